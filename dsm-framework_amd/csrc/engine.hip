@@ -1,0 +1,1225 @@
+// engine.hip -- frontier engine: FM-index backward-search enumeration + cross-sample merge (gfx950).
+//
+// The reference walks each sample's suffix trie depth first, one LF call at a time
+// (EnumerateQuery::nextSymbol, EnumerateQuery.cpp:151-238) and merges the per-sample streams in a
+// single-threaded server (metaserver.cpp:269-486).  Here the trie of one prefix is expanded level by
+// level: every node of the current frontier is expanded by one GPU thread (all four children, all
+// left-extension intervals, fmin test and left-char code fused: "expand_kernel", the LF-step kernel),
+// samples exchange one [4F] frequency column per level (one all-gather), and the DFS order of the
+// reference's output is recovered at the end from subtree sizes (prefix sums over the levels).
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+#include "scan.h"
+
+namespace dsm {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <typename P>
+struct RankCache {
+    u64 bi;
+    Blk16 r;
+};
+
+// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x)
+template <typename P>
+__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache<P>& rc, u64 x, P out[4], u32& lines) {
+    u64 bi = x >> BLK_SHIFT;
+    if (bi != rc.bi) {
+        load_blk(ix.blk, bi, rc.r);
+        rc.bi = bi;
+        ++lines;
+    }
+    u32 c4[4];
+    blk_counts(rc.r, (u32)(x & (BLK_SYMS - 1)), c4);
+    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + rc.r.cnt[c] + c4[c]);
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// record layout (struct of arrays): field f of node i lives at rec[f * cap + i]
+//   0 sp  1 ep  2..5 extmin[A,C,G,T]  6..9 extmax[A,C,G,T]     (EnumerateQuery.h:44-45, Query.h:110-111)
+// a node that is absent in this sample has sp > ep (sp = 1, ep = 0); an empty ext has min = 1, max = 0.
+constexpr int REC_FIELDS = 10;
+
+struct ExpandArgs {
+    u32 F;            // frontier width
+    u32 cap;          // record capacity (stride)
+    u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
+    u32 fmin;
+    u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
+    u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
+    u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
+};
+
+// counters[0]=reported [1]=lf_steps [2]=rank_ops [3]=block lines fetched
+template <typename P>
+__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const P* __restrict__ rec, P* __restrict__ tmp,
+                                                     P* __restrict__ cfreq, u8* __restrict__ cleft, ExpandArgs a,
+                                                     u64* __restrict__ counters) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 n_rep = 0, n_lf = 0, n_rank = 0;
+    u32 lines = 0;
+    if (i < a.F) {
+        const P sp = rec[0 * (size_t)a.cap + i], ep = rec[1 * (size_t)a.cap + i];
+        const size_t slot0 = (size_t)i * 4;
+        if (sp > ep) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cfreq[slot0 + c] = 0;
+        } else {
+            P emin[4], emax[4];
+            u32 ne = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                emin[k] = rec[(size_t)(2 + k) * a.cap + i];
+                emax[k] = rec[(size_t)(6 + k) * a.cap + i];
+                ne += emin[k] <= emax[k];
+            }
+            RankCache<P> rc;
+            rc.bi = ~0ull;
+            P Rsp[4], Rep[4], Rlo[4][4], Rhi[4][4];
+            rank4<P>(ix, rc, (u64)sp, Rsp, lines);  // LF(c, sp-1)
+            const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (emin[k] <= emax[k]) {
+                    rank4<P>(ix, rc, (u64)emin[k], Rlo[k], lines);
+                    rank4<P>(ix, rc, (u64)emax[k] + 1, Rhi[k], lines);
+                }
+            }
+            rank4<P>(ix, rc, (u64)ep + 1, Rep, lines);  // LF(c, ep)
+            const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
+            if (single && a.allowed) n_rank += a.access_cost[lcode];
+            const size_t tcap = (size_t)a.cap * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                P f = 0;
+                if ((a.allowed >> c) & 1u) {
+                    const P nsp = Rsp[c], nep = Rep[c] - 1;
+                    const bool nonempty = nsp <= nep;
+                    if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
+                    if (nonempty) {
+                        if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
+                        if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
+                            f = nep - nsp + 1;
+                            bool any = false, matches = false;
+                            u32 lc = 0;
+                            const size_t s = slot0 + c;
+                            tmp[0 * tcap + s] = nsp;
+                            tmp[1 * tcap + s] = nep;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                P cmin = 1, cmax = 0;
+                                if (emin[k] <= emax[k]) {  // EnumerateQuery.cpp:44-55
+                                    P lo = Rlo[k][c], hi = Rhi[k][c] - 1;
+                                    if (lo <= hi) {
+                                        cmin = lo; cmax = hi;
+                                        any = true; lc = k;
+                                        if (lo == nsp && hi == nep) matches = true;
+                                    }
+                                }
+                                tmp[(size_t)(2 + k) * tcap + s] = cmin;
+                                tmp[(size_t)(6 + k) * tcap + s] = cmax;
+                            }
+                            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
+                            cleft[s] = matches ? (u8)(1 + lc) : (any ? (u8)5 : (u8)0);
+                            ++n_rep;
+                        }
+                    }
+                }
+                cfreq[slot0 + c] = f;
+            }
+        }
+    }
+    u64 s0 = wave_sum_u64(n_rep), s1 = wave_sum_u64(n_lf), s2 = wave_sum_u64(n_rank), s3 = wave_sum_u64((u64)lines);
+    if ((threadIdx.x & 63) == 0) {
+        if (s0) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)s0);
+        if (s1) atomicAdd((unsigned long long*)&counters[1], (unsigned long long)s1);
+        if (s2) atomicAdd((unsigned long long*)&counters[2], (unsigned long long)s2);
+        if (s3) atomicAdd((unsigned long long*)&counters[3], (unsigned long long)s3);
+    }
+}
+
+// view of one exchange buffer: rank-major, inside a rank [nlocal][slots] P then [nlocal][slots] u8
+struct Xchg {
+    const u8* base;
+    u64 bpr;      // bytes per rank
+    u32 nlocal;
+    u32 d;        // total samples = world * nlocal
+    u64 slots;    // 4F of the level that produced it
+};
+template <typename P>
+__device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 slot) {
+    const u8* rb = x.base + (u64)(g / x.nlocal) * x.bpr;
+    return reinterpret_cast<const P*>(rb)[(u64)(g % x.nlocal) * x.slots + slot];
+}
+template <typename P>
+__device__ __forceinline__ u8 x_left(const Xchg& x, u32 g, u64 slot) {
+    const u8* rb = x.base + (u64)(g / x.nlocal) * x.bpr + (u64)x.nlocal * x.slots * sizeof(P);
+    return rb[(u64)(g % x.nlocal) * x.slots + slot];
+}
+
+// per slot: alive in any sample?  number of samples, merged left char (metaserver.cpp:383-387)
+template <typename P>
+__global__ void flags_kernel(Xchg x, u32* __restrict__ flag, u16* __restrict__ nTslot, u8* __restrict__ mleft_slot) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= x.slots) return;
+    u32 nT = 0;
+    u8 ml = 0xFF;
+    for (u32 g = 0; g < x.d; ++g) {
+        if (x_freq<P>(x, g, j) != 0) {
+            ++nT;
+            u8 l = x_left<P>(x, g, j);
+            ml = ml == 0xFF ? l : (ml == l ? ml : (u8)5);
+        }
+    }
+    flag[j] = nT ? 1u : 0u;
+    nTslot[j] = (u16)nT;
+    mleft_slot[j] = ml;
+}
+
+// new union nodes: parent link, symbol, #samples, merged left char, slot in the exchange buffer
+__global__ void node_kernel(u64 slots, const u32* __restrict__ flag, const u32* __restrict__ newidx, const u16* __restrict__ nTslot,
+                            const u8* __restrict__ mleft_slot, u32* __restrict__ parent, u8* __restrict__ sym, u16* __restrict__ nT,
+                            u8* __restrict__ mleft, u32* __restrict__ slot_of) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= slots || !flag[j]) return;
+    u32 v = newidx[j];
+    parent[v] = (u32)(j >> 2);
+    sym[v] = (u8)(j & 3);
+    nT[v] = nTslot[j];
+    mleft[v] = mleft_slot[j];
+    slot_of[v] = (u32)j;
+}
+
+// per parent: first child index, number of children, "single child carrying every reader" (metaserver.cpp:416-417)
+__global__ void parent_kernel(u32 F, const u32* __restrict__ flag, const u32* __restrict__ newidx, const u16* __restrict__ nTslot,
+                              const u16* __restrict__ nT, u32* __restrict__ firstchild, u8* __restrict__ nchild, u8* __restrict__ samechild) {
+    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= F) return;
+    u32 nc = 0, last = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (flag[(u64)u * 4 + c]) { ++nc; last = c; }
+    firstchild[u] = newidx[(u64)u * 4];
+    nchild[u] = (u8)nc;
+    samechild[u] = (nc == 1 && nTslot[(u64)u * 4 + last] == nT[u]) ? 1 : 0;
+}
+
+// move the surviving children of one local sample from the temp slots to the next frontier
+template <typename P>
+__global__ void copy_kernel(u64 slots, u32 cap, const u32* __restrict__ flag, const u32* __restrict__ newidx,
+                            const P* __restrict__ cfreq, const P* __restrict__ tmp, P* __restrict__ next) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= slots || !flag[j]) return;
+    u32 v = newidx[j];
+    if (cfreq[j] != 0) {
+        const size_t tcap = (size_t)cap * 4;
+#pragma unroll
+        for (int f = 0; f < REC_FIELDS; ++f) next[(size_t)f * cap + v] = tmp[(size_t)f * tcap + j];
+    } else {
+        next[v] = 1;
+        next[(size_t)cap + v] = 0;
+    }
+}
+
+// stream mode keeps freq and left char of every node
+template <typename P>
+__global__ void keep_kernel(u64 slots, const u32* __restrict__ flag, const u32* __restrict__ newidx, const P* __restrict__ cfreq,
+                            const u8* __restrict__ cleft, P* __restrict__ freq, u8* __restrict__ left) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= slots || !flag[j]) return;
+    u32 v = newidx[j];
+    freq[v] = cfreq[j];
+    left[v] = cleft[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Iteration order of the reference's std::unordered_set<unsigned> reader sets (metaserver.cpp:23).
+// With at most 13 samples libstdc++ keeps 13 buckets and every id its own bucket, so a set iterates in
+// REVERSE insertion order; the insertion sequence into children[c] follows readChildren() round by
+// round (metaserver.cpp:159-189, 322-339).  Orders are nibble-packed, first iterated id in bits 0-3.
+// ---------------------------------------------------------------------------------------------
+template <typename P>
+__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, const u32* __restrict__ flag,
+                             const u32* __restrict__ newidx, u64* __restrict__ order_next) {
+    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= F) return;
+    const u32 cnt = nT[u];
+    const u64 ord = order[u];
+    u32 mask[16];
+    for (u32 k = 0; k < cnt; ++k) {
+        u32 r = (u32)((ord >> (4 * k)) & 15);
+        u32 m = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m |= (x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
+        mask[k] = m;  // indexed by position in the parent's order
+    }
+    u64 ins[4] = {0, 0, 0, 0};
+    u32 icnt[4] = {0, 0, 0, 0};
+    // round 1: every reader of the parent reads its first child
+    for (u32 k = 0; k < cnt; ++k) {
+        u32 m = mask[k];
+        if (m) {
+            int f = __ffs(m) - 1;
+            ins[f] |= (u64)((ord >> (4 * k)) & 15) << (4 * icnt[f]);
+            ++icnt[f];
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (!icnt[i]) continue;
+        // iteration order of children[i] = reverse insertion order
+        u64 rev = 0;
+        for (u32 k = 0; k < icnt[i]; ++k) rev |= ((ins[i] >> (4 * k)) & 15) << (4 * (icnt[i] - 1 - k));
+        order_next[newidx[(u64)u * 4 + i]] = rev;
+        // next round: the readers of this child (in its iteration order) read their next child
+        for (u32 k = 0; k < icnt[i]; ++k) {
+            u32 r = (u32)((rev >> (4 * k)) & 15);
+            // find r's mask: position of r in the parent's order
+            u32 m = 0;
+            for (u32 q = 0; q < cnt; ++q)
+                if (((ord >> (4 * q)) & 15) == r) m = mask[q];
+            m &= ~((2u << i) - 1);
+            if (m) {
+                int g = __ffs(m) - 1;
+                ins[g] |= (u64)r << (4 * icnt[g]);
+                ++icnt[g];
+            }
+        }
+    }
+}
+
+struct FilterArgs {
+    u32 F;
+    u32 depth;
+    u32 d;
+    u32 pmin, pmax, mindepth;
+    double emin, emax;
+    u32 exact_order;  // order[] valid (1 < d <= 13)
+};
+
+// output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
+// within 1e-9 of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
+template <typename P>
+__global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u8* __restrict__ mleft,
+                              const u8* __restrict__ nchild, const u8* __restrict__ samechild, u32* __restrict__ cand, u32* __restrict__ cand_pairs) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.F) return;
+    bool out = true;
+    const u32 t = nT[v];
+    if (a.depth < a.mindepth) out = false;
+    if (a.pmax != 0 && t > a.pmax) out = false;
+    if (t < a.pmin) out = false;
+    if (nchild[v] == 1 && samechild[v]) out = false;
+    const u8 l = mleft[v];
+    if (l >= 1 && l <= 4) out = false;
+    if (out && a.emax > 0) {
+        u64 sumN = a.d;
+        double s = 0;
+        const u64 j = slot_of[v];
+        for (u32 g = 0; g < a.d; ++g) {
+            u64 f = (u64)x_freq<P>(x, g, j);
+            if (f) {
+                sumN += f;
+                s += (double)(f + 1) * log2((double)(f + 1));
+            }
+        }
+        double e = log2((double)sumN) - s / (double)sumN;
+        if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
+    }
+    cand[v] = out ? 1u : 0u;
+    cand_pairs[v] = out ? t : 0u;
+}
+
+// store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
+template <typename P>
+__global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u64* __restrict__ order,
+                                  const u32* __restrict__ cand, const u32* __restrict__ cidx, const u32* __restrict__ poff,
+                                  u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.F || !cand[v]) return;
+    const u32 k = cidx[v];
+    u32 o = poff[v];
+    cand_node[k] = v;
+    cand_poff[k] = o;
+    const u64 j = slot_of[v];
+    if (a.exact_order) {
+        const u64 ord = order[v];
+        const u32 cnt = nT[v];
+        for (u32 q = 0; q < cnt; ++q) {
+            u32 g = (u32)((ord >> (4 * q)) & 15);
+            ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
+        }
+    } else {
+        for (u32 g = 0; g < a.d; ++g) {
+            u64 f = (u64)x_freq<P>(x, g, j);
+            if (f) { ids[o] = g; freqs[o] = f; ++o; }
+        }
+    }
+}
+
+// ---- subtree aggregates over the retained levels ------------------------------------------------
+// bottom-up: agg[v] = own[v] + sum over children agg_child
+template <typename T, typename OwnT>
+__global__ void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const u8* __restrict__ nchild,
+                          const T* __restrict__ child_agg, T* __restrict__ agg) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    T s = own ? (T)own[v] : (T)1;
+    u32 fc = firstchild[v], nc = nchild[v];
+    for (u32 k = 0; k < nc; ++k) s += child_agg[fc + k];
+    agg[v] = s;
+}
+// top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]
+template <typename T>
+__global__ void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild, const u8* __restrict__ nchild,
+                            const T* __restrict__ child_agg, T* __restrict__ child_start) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    T s = start[v] + lead;
+    u32 fc = firstchild[v], nc = nchild[v];
+    for (u32 k = 0; k < nc; ++k) {
+        child_start[fc + k] = s;
+        s += child_agg[fc + k];
+    }
+}
+
+// candidate k of a level gets its post-order rank among all candidates of the chunk
+__global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, const u32* __restrict__ start, const u32* __restrict__ sub,
+                                 u32 level, u32* __restrict__ t_level, u32* __restrict__ t_cidx) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncand) return;
+    u32 v = cand_node[k];
+    u32 r = start[v] + sub[v] - 1;
+    t_level[r] = level;
+    t_cidx[r] = k;
+}
+
+struct LevelDev {
+    const u32* parent;
+    const u8* sym;
+    const u32* cand_node;
+    const u32* cand_poff;
+    const u32* ids;
+    const u64* freqs;
+    u32 ncand;
+    u32 npairs;
+};
+
+__global__ void tuple_size_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
+                                  u32* __restrict__ plen, u32* __restrict__ npair) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nt) return;
+    const LevelDev L = lv[t_level[r]];
+    u32 k = t_cidx[r];
+    u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
+    plen[r] = t_level[r];
+    npair[r] = e - L.cand_poff[k];
+}
+
+__global__ void tuple_fill_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
+                                  const u32* __restrict__ path_off, const u32* __restrict__ pair_off, char* __restrict__ paths,
+                                  u32* __restrict__ ids, u64* __restrict__ freqs) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nt) return;
+    u32 lvl = t_level[r];
+    const LevelDev L = lv[lvl];
+    u32 k = t_cidx[r];
+    u32 b = L.cand_poff[k];
+    u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
+    u32 o = pair_off[r];
+    for (u32 q = b; q < e; ++q, ++o) { ids[o] = L.ids[q]; freqs[o] = L.freqs[q]; }
+    u32 v = L.cand_node[k];
+    u32 po = path_off[r];
+    for (u32 l = lvl; l >= 1; --l) {
+        paths[po + l - 1] = "ACGT"[lv[l].sym[v]];
+        v = lv[l].parent[v];
+    }
+}
+
+// ---- wire stream (ClientSocket.h:20-39) ---------------------------------------------------------
+__device__ __forceinline__ u32 varint_len(u64 u) {
+    if (u < 128) return 1;
+    return 1 + (u32)((64 - __clzll((long long)u) + 7) >> 3);
+}
+__device__ __forceinline__ u32 put_varint(u8* p, u64 u) {
+    if (u < 128) { p[0] = (u8)(u | 0x80); return 1; }
+    u32 l = (u32)((64 - __clzll((long long)u) + 7) >> 3);
+    p[0] = (u8)l;
+    for (u32 k = 0; k < l; ++k) p[1 + k] = (u8)(u >> (8 * k));
+    return 1 + l;
+}
+
+// own bytes of a node: '(' sym + varint(freq) + ['R' varint(reported)] + left + ')'
+template <typename P>
+__global__ void stream_own_kernel(u32 F, u32 depth, u64 rbase, const P* __restrict__ freq, const u64* __restrict__ pre, const u64* __restrict__ sz,
+                                  u64* __restrict__ own) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    u64 b = 2 + varint_len((u64)freq[v]) + 2;
+    if (depth <= 6) b += 1 + varint_len(rbase + pre[v] + sz[v]);  // EnumerateQuery.cpp:214-218
+    own[v] = b;
+}
+
+template <typename P>
+__global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u8* __restrict__ sym, const P* __restrict__ freq, const u8* __restrict__ left,
+                                    const u64* __restrict__ pre, const u64* __restrict__ sz, const u64* __restrict__ off, const u64* __restrict__ bytes,
+                                    const u64* __restrict__ own, u8* __restrict__ out) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    u8* p = out + off[v];
+    p[0] = '(';
+    p[1] = (u8)"ACGT"[sym[v]];
+    u8* q = out + off[v] + bytes[v] - (own[v] - 2);
+    q += put_varint(q, (u64)freq[v]);
+    if (depth <= 6) { *q++ = 'R'; q += put_varint(q, rbase + pre[v] + sz[v]); }
+    *q++ = (u8)"0ACGTN"[left[v]];
+    *q = ')';
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+    u8* base = nullptr;
+    size_t cap = 0, off = 0;
+    template <class T> T* get(size_t n) {
+        size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct LevelHost {
+    u32 n = 0;
+    u32* parent = nullptr;
+    u8* sym = nullptr;
+    u32* firstchild = nullptr;
+    u8* nchild = nullptr;
+    // mine
+    u32* cand_flag = nullptr;  // per node
+    u32 ncand = 0, npairs = 0;
+    u32* cand_node = nullptr;
+    u32* cand_poff = nullptr;
+    u32* ids = nullptr;
+    u64* freqs = nullptr;
+    u32* sub = nullptr;
+    // stream
+    void* freq = nullptr;
+    u8* left = nullptr;
+    u64* sz = nullptr;
+    u64* pre = nullptr;
+    u64* own = nullptr;
+    u64* bytes = nullptr;
+    u64* off = nullptr;
+};
+
+static inline dim3 grid_for(u64 n, int t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
+
+#define ARENA_GET(var, T, n)                                                                        \
+    do {                                                                                            \
+        (var) = arena.get<T>(n);                                                                    \
+        if (!(var)) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes"); \
+    } while (0)
+
+template <typename P>
+class Engine {
+  public:
+    std::vector<const dsm_index*> idx;
+    dsm_params prm;
+    bool stream_mode = false;
+    int nlocal = 0, world = 1, rank = 0;
+    u32 d = 1;
+    hipStream_t st = 0;
+    int device = 0;
+
+    // frontier buffers
+    u32 Fcap = 0;
+    std::vector<P*> rec[2];
+    std::vector<P*> tmp;
+    u8* xsend = nullptr;
+    u8* xrecv[2] = {nullptr, nullptr};
+    bool own_x = false;
+    u64 bpr_cap = 0;
+    u32 *flag = nullptr, *newidx = nullptr, *scan_tmp = nullptr;
+    u16 *nTslot = nullptr, *nT[2] = {nullptr, nullptr};
+    u8 *mleft_slot = nullptr, *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
+    u32* slot_of[2] = {nullptr, nullptr};
+    u64* order[2] = {nullptr, nullptr};
+    u32 *cand_idx = nullptr, *cand_pairs = nullptr, *cand_poff_node = nullptr;
+    u64* d_counters = nullptr;
+    u32* d_totals = nullptr;
+    u32* h_totals = nullptr;  // pinned
+    std::vector<void*> owned;
+    Arena arena;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+    dsm_stats stats;
+
+    ~Engine() {
+        for (void* p : owned) (void)hipFree(p);
+        if (h_totals) (void)hipHostFree(h_totals);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (evA) (void)hipEventDestroy(evA);
+        if (evB) (void)hipEventDestroy(evB);
+    }
+
+    template <class T> int dalloc(T*& p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+        if (e != hipSuccess) return fail(DSM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        owned.push_back(q);
+        p = (T*)q;
+        return 0;
+    }
+
+    int init(dsm_index* const* ix, int n, const dsm_params& p, bool stream) {
+        memset(&stats, 0, sizeof stats);
+        prm = p;
+        stream_mode = stream;
+        nlocal = n;
+        world = p.world_size > 1 ? (int)p.world_size : 1;
+        rank = world > 1 ? (int)p.rank : 0;
+        if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
+        if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
+        d = (u32)(world * nlocal);
+        if (d > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
+        st = (hipStream_t)p.stream;
+        device = ix[0]->device;
+        for (int k = 0; k < n; ++k) {
+            if (ix[k]->device != device) return fail(DSM_E_INVAL, "all local indexes must live on one device");
+            idx.push_back(ix[k]);
+        }
+        DSM_HIP(hipSetDevice(device));
+        size_t free_b = 0, total_b = 0;
+        DSM_HIP(hipMemGetInfo(&free_b, &total_b));
+        // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
+        // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
+        u64 nsum = 0, nmax = 0;
+        for (int k = 0; k < n; ++k) { nsum += ix[k]->meta.n; nmax = ix[k]->meta.n > nmax ? ix[k]->meta.n : nmax; }
+        const u64 fbound = (world > 1 ? (u64)d * nmax : nsum) + 16;
+        u64 budget = p.arena_bytes ? p.arena_bytes : (u64)(free_b * 0.7);
+        if (!p.arena_bytes) {
+            u64 want = (256ull << 20) + 900ull * nsum * (u64)world;
+            if (want < budget) budget = want;
+        }
+        if (budget > free_b) budget = (u64)(free_b * 0.9);
+        // bytes per unit of frontier capacity
+        u64 perF = (u64)nlocal * (2 * REC_FIELDS + 4 * REC_FIELDS) * sizeof(P)  // rec x2 + tmp
+                   + (u64)nlocal * 4 * (sizeof(P) + 1)                           // send
+                   + 2ull * d * 4 * (sizeof(P) + 1)                              // recv x2
+                   + 4 * (4 + 4 + 2 + 1) + 2 * (2 + 1 + 4 + 8) + 1 + 12 + 64;
+        u64 fc = budget / 3 / perF;
+        if (fc > (1u << 27)) fc = 1u << 27;
+        if (fc > fbound) fc = fbound;
+        if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
+        Fcap = (u32)fc;
+        const u64 slots = (u64)Fcap * 4;
+        for (int s = 0; s < nlocal; ++s) {
+            P *a, *b, *t;
+            if (int rc = dalloc(a, (size_t)REC_FIELDS * Fcap)) return rc;
+            if (int rc = dalloc(b, (size_t)REC_FIELDS * Fcap)) return rc;
+            if (int rc = dalloc(t, (size_t)REC_FIELDS * slots)) return rc;
+            rec[0].push_back(a); rec[1].push_back(b); tmp.push_back(t);
+        }
+        bpr_cap = (u64)nlocal * slots * (sizeof(P) + 1);
+        if (p.exchange_send && p.exchange_recv && world > 1) {
+            if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
+            // caller-owned buffers bound the frontier as well; recv is used as two halves
+            u64 cap_slots = p.exchange_bytes / ((u64)nlocal * (sizeof(P) + 1));
+            if (cap_slots / 4 < Fcap) Fcap = (u32)(cap_slots / 4);
+            bpr_cap = p.exchange_bytes;
+            xsend = (u8*)p.exchange_send;
+            xrecv[0] = (u8*)p.exchange_recv;
+            if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
+        } else {
+            own_x = true;
+            if (int rc = dalloc(xrecv[0], (size_t)world * bpr_cap)) return rc;
+            if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
+            if (world > 1) { if (int rc = dalloc(xsend, (size_t)bpr_cap)) return rc; }
+        }
+        if (int rc = dalloc(flag, slots)) return rc;
+        if (int rc = dalloc(newidx, slots)) return rc;
+        if (int rc = dalloc(scan_tmp, scan_tmp_elems(slots) + 8)) return rc;
+        if (int rc = dalloc(nTslot, slots)) return rc;
+        if (int rc = dalloc(mleft_slot, slots)) return rc;
+        for (int k = 0; k < 2; ++k) {
+            if (int rc = dalloc(nT[k], Fcap)) return rc;
+            if (int rc = dalloc(mleft[k], Fcap)) return rc;
+            if (int rc = dalloc(slot_of[k], Fcap)) return rc;
+            if (int rc = dalloc(order[k], Fcap)) return rc;
+        }
+        if (int rc = dalloc(samechild, Fcap)) return rc;
+        if (int rc = dalloc(cand_idx, Fcap)) return rc;
+        if (int rc = dalloc(cand_pairs, Fcap)) return rc;
+        if (int rc = dalloc(cand_poff_node, Fcap)) return rc;
+        if (int rc = dalloc(d_counters, 8)) return rc;
+        if (int rc = dalloc(d_totals, 8)) return rc;
+        DSM_HIP(hipHostMalloc((void**)&h_totals, 8 * sizeof(u32)));
+        size_t used = 0;
+        {
+            size_t f2 = 0, t2 = 0;
+            DSM_HIP(hipMemGetInfo(&f2, &t2));
+            used = free_b - f2;
+        }
+        u64 arena_b = budget > used ? budget - used : 0;
+        if (arena_b < (64u << 20)) arena_b = 64u << 20;
+        if (int rc = dalloc(arena.base, arena_b)) return rc;
+        arena.cap = arena_b;
+        DSM_HIP(hipEventCreate(&ev0));
+        DSM_HIP(hipEventCreate(&ev1));
+        DSM_HIP(hipEventCreate(&evA));
+        DSM_HIP(hipEventCreate(&evB));
+        return 0;
+    }
+
+    Xchg xview(int which, u64 slots, u64 bpr) const {
+        Xchg x;
+        x.base = xrecv[which];
+        x.bpr = bpr;
+        x.nlocal = (u32)nlocal;
+        x.d = d;
+        x.slots = slots;
+        return x;
+    }
+
+    int read_totals(int n) {
+        DSM_HIP(hipMemcpyAsync(h_totals, d_totals, n * sizeof(u32), hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+
+    // Runs one prefix.  mine: tuples to `tsink`; stream: wire bytes to `bsink`.
+    int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx) {
+        const std::string prefix = prefix_c ? prefix_c : "";
+        for (char ch : prefix)
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
+                return fail(DSM_E_INVAL, "prefix must be over A,C,G,T");  // anything else has an empty LF interval: nothing to send
+        DSM_HIP(hipSetDevice(device));
+        arena.off = 0;
+        std::vector<LevelHost> L;
+        L.reserve(512);
+        DSM_HIP(hipMemsetAsync(d_counters, 0, 8 * sizeof(u64), st));
+        DSM_HIP(hipEventRecord(ev0, st));
+        float expand_ms = 0;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> evpairs;
+
+        // ---- level 0: the root (EnumerateQuery::enumerate, EnumerateQuery.cpp:9-37) --------------
+        const char* bases = "ACGT";
+        for (int s = 0; s < nlocal; ++s) {
+            const IndexMeta& m = idx[s]->meta;
+            P h[REC_FIELDS];
+            h[0] = 0;
+            h[1] = (P)(m.n - 1);
+            for (int a = 0; a < 4; ++a) {
+                u64 lo = m.C[(int)bases[a]], hi = m.C[(int)bases[a]] + m.codes[(int)bases[a]].count;  // LF(a,-1), LF(a,n-1)
+                if (lo <= hi - 1 && m.codes[(int)bases[a]].count) { h[2 + a] = (P)lo; h[6 + a] = (P)(hi - 1); }
+                else { h[2 + a] = 1; h[6 + a] = 0; }
+            }
+            for (int f = 0; f < REC_FIELDS; ++f)
+                DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Fcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
+            stats.lf_steps += 8;
+            for (int a = 0; a < 4; ++a) stats.rank_ops += 2 * m.lfcost[a];
+        }
+        {
+            LevelHost root;
+            root.n = 1;
+            ARENA_GET(root.parent, u32, 1);
+            ARENA_GET(root.sym, u8, 1);
+            ARENA_GET(root.firstchild, u32, 1);
+            ARENA_GET(root.nchild, u8, 1);
+            L.push_back(root);
+            u16 rootT = (u16)d;
+            DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
+            // root reader set: ids inserted 0..d-1, iterated in reverse (d <= 13)
+            u64 ord = 0;
+            for (u32 k = 0; k < d && k < 16; ++k) ord |= (u64)(d - 1 - k) << (4 * k);
+            DSM_HIP(hipMemcpyAsync(order[0], &ord, sizeof(u64), hipMemcpyHostToDevice, st));
+        }
+        const bool exact_order = d >= 2 && d <= 13;
+        stats.pair_order_exact = (d <= 13) ? 1 : 0;
+
+        int cur = 0;      // rec / nT / order ping-pong index of the current level
+        int xcur = 0;     // exchange buffer that will receive the current level's children
+        u32 F = 1;
+        u32 depth = 0;
+        u64 prev_slots = 0, prev_bpr = 0;  // exchange view that holds the freqs of the current level's nodes
+        while (true) {
+            // ---- expand ---------------------------------------------------------------------------
+            const u64 slots = (u64)F * 4;
+            const u64 bpr = (u64)nlocal * slots * (sizeof(P) + 1);
+            u8* send = world > 1 ? xsend : xrecv[xcur];
+            ExpandArgs ea;
+            memset(&ea, 0, sizeof ea);
+            ea.F = F; ea.cap = Fcap; ea.fmin = prm.fmin;
+            if (depth < prefix.size()) {
+                const char* q = strchr(bases, prefix[depth]);
+                ea.allowed = 1u << (q - bases);
+                ea.symbol_phase = 0;
+            } else {
+                ea.allowed = depth >= prm.maxdepth ? 0u : 15u;  // EnumerateQuery.cpp:153
+                ea.symbol_phase = 1;
+            }
+            hipEvent_t ea0, ea1;
+            DSM_HIP(hipEventCreate(&ea0));
+            DSM_HIP(hipEventCreate(&ea1));
+            evpairs.push_back({ea0, ea1});
+            DSM_HIP(hipEventRecord(ea0, st));
+            for (int s = 0; s < nlocal; ++s) {
+                const IndexMeta& m = idx[s]->meta;
+                for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
+                for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
+                P* cf = reinterpret_cast<P*>(send) + (size_t)s * slots;
+                u8* cl = send + (size_t)nlocal * slots * sizeof(P) + (size_t)s * slots;
+                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rec[cur][s], tmp[s], cf, cl, ea, d_counters);
+                ++stats.expand_launches;
+            }
+            DSM_HIP(hipEventRecord(ea1, st));
+            DSM_HIP(hipGetLastError());
+            // ---- exchange: one all-gather per level ----------------------------------------------
+            if (world > 1) {
+                int rc = prm.allgather(prm.allgather_ctx, xsend, xrecv[xcur], (size_t)bpr, (void*)st);
+                if (rc) return fail(DSM_E_SINK, "allgather callback failed");
+            }
+            Xchg x = xview(xcur, slots, bpr);
+            // ---- union frontier of the next level -------------------------------------------------
+            hipLaunchKernelGGL((flags_kernel<P>), grid_for(slots), dim3(256), 0, st, x, flag, nTslot, mleft_slot);
+            exclusive_scan<u32, u32>(flag, newidx, slots, scan_tmp, d_totals, st);
+            if (int rc = read_totals(1)) return rc;
+            const u32 Fn = h_totals[0];
+            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+            const int nxt = cur ^ 1;
+            LevelHost& me = L[depth];
+            LevelHost child;
+            child.n = Fn;
+            hipLaunchKernelGGL(parent_kernel, grid_for(F), dim3(256), 0, st, F, flag, newidx, nTslot, nT[cur], me.firstchild, me.nchild, samechild);
+            if (Fn) {
+                ARENA_GET(child.parent, u32, Fn);
+                ARENA_GET(child.sym, u8, Fn);
+                ARENA_GET(child.firstchild, u32, Fn);
+                ARENA_GET(child.nchild, u8, Fn);
+                hipLaunchKernelGGL(node_kernel, grid_for(slots), dim3(256), 0, st, slots, flag, newidx, nTslot, mleft_slot, child.parent, child.sym,
+                                   nT[nxt], mleft[nxt], slot_of[nxt]);
+                for (int s = 0; s < nlocal; ++s) {
+                    const P* cf = reinterpret_cast<const P*>(x.base + (u64)rank * bpr) + (size_t)s * slots;
+                    hipLaunchKernelGGL((copy_kernel<P>), grid_for(slots), dim3(256), 0, st, slots, Fcap, flag, newidx, cf, tmp[s], rec[nxt][s]);
+                }
+                if (stream_mode) {
+                    P* fq;
+                    ARENA_GET(fq, P, Fn);
+                    child.freq = fq;
+                    ARENA_GET(child.left, u8, Fn);
+                    const P* cf = reinterpret_cast<const P*>(x.base);
+                    const u8* cl = x.base + (u64)nlocal * slots * sizeof(P);
+                    hipLaunchKernelGGL((keep_kernel<P>), grid_for(slots), dim3(256), 0, st, slots, flag, newidx, cf, cl, fq, child.left);
+                }
+                if (exact_order)
+                    hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], flag, newidx, order[nxt]);
+            }
+            // ---- output predicates for the nodes of THIS level (their children are known now) -----
+            if (!stream_mode && depth >= 1) {
+                FilterArgs fa;
+                fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
+                fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = exact_order ? 1u : 0u;
+                Xchg xp = xview(xcur ^ 1, prev_slots, prev_bpr);
+                ARENA_GET(me.cand_flag, u32, F);
+                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, slot_of[cur], nT[cur], mleft[cur], me.nchild, samechild,
+                                   me.cand_flag, cand_pairs);
+                exclusive_scan<u32, u32>(me.cand_flag, cand_idx, F, scan_tmp, d_totals, st);
+                exclusive_scan<u32, u32>(cand_pairs, cand_poff_node, F, scan_tmp, d_totals + 1, st);
+                if (int rc = read_totals(2)) return rc;
+                me.ncand = h_totals[0];
+                me.npairs = h_totals[1];
+                if (me.ncand) {
+                    ARENA_GET(me.cand_node, u32, me.ncand);
+                    ARENA_GET(me.cand_poff, u32, me.ncand);
+                    ARENA_GET(me.ids, u32, me.npairs);
+                    ARENA_GET(me.freqs, u64, me.npairs);
+                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, slot_of[cur], nT[cur], order[cur], me.cand_flag, cand_idx,
+                                       cand_poff_node, me.cand_node, me.cand_poff, me.ids, me.freqs);
+                }
+                stats.candidates += me.ncand;
+            }
+            DSM_HIP(hipGetLastError());
+            stats.union_nodes += depth >= 1 ? F : 0;
+            if (F > stats.max_frontier) stats.max_frontier = F;
+            ++stats.levels;
+            if (!Fn) break;
+            L.push_back(child);
+            prev_slots = slots; prev_bpr = bpr;
+            cur = nxt;
+            xcur ^= 1;
+            F = Fn;
+            ++depth;
+            if (L.size() > 60000) return fail(DSM_E_CAPACITY, "trie deeper than 60000 levels");
+        }
+        const u32 nlev = (u32)L.size();  // levels 0..nlev-1, level l holds the nodes of depth l
+
+        int rc = stream_mode ? finish_stream(L, nlev, bsink, ctx) : finish_mine(L, nlev, tsink, ctx);
+        if (rc) return rc;
+
+        DSM_HIP(hipEventRecord(ev1, st));
+        DSM_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        DSM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        stats.device_ms += ms;
+        for (auto& pr : evpairs) {
+            float t = 0;
+            DSM_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+            expand_ms += t;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        stats.expand_ms += expand_ms;
+        u64 hc[4];
+        DSM_HIP(hipMemcpy(hc, d_counters, sizeof hc, hipMemcpyDeviceToHost));
+        stats.reported += hc[0];
+        stats.lf_steps += hc[1];
+        stats.rank_ops += hc[2];
+        lines_fetched += hc[3];
+        return 0;
+    }
+    u64 lines_fetched = 0;
+
+    // ---- mine: post-order ranks of the candidates, tuple assembly, exact entropy on the host ------
+    int finish_mine(std::vector<LevelHost>& L, u32 nlev, dsm_tuple_sink sink, void* ctx) {
+        u64 ncand_total = 0;
+        for (u32 l = 1; l < nlev; ++l) ncand_total += L[l].ncand;
+        if (ncand_total == 0) return 0;
+        if (ncand_total > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "more than 2^32 candidate tuples in one prefix: use a longer prefix");
+        const u32 nt = (u32)ncand_total;
+        // bottom-up: candidates in subtree
+        for (u32 l = nlev; l-- > 1;) {
+            ARENA_GET(L[l].sub, u32, L[l].n);
+            const u32* child_sub = l + 1 < nlev ? L[l + 1].sub : nullptr;
+            hipLaunchKernelGGL((up_kernel<u32, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, L[l].nchild, child_sub,
+                               L[l].sub);
+        }
+        // top-down: start offsets, two rolling arrays
+        u32 *t_level, *t_cidx;
+        ARENA_GET(t_level, u32, nt);
+        ARENA_GET(t_cidx, u32, nt);
+        u32 maxn = 1;
+        for (u32 l = 0; l < nlev; ++l) maxn = L[l].n > maxn ? L[l].n : maxn;
+        u32* startbuf[2];
+        ARENA_GET(startbuf[0], u32, maxn);
+        ARENA_GET(startbuf[1], u32, maxn);
+        DSM_HIP(hipMemsetAsync(startbuf[0], 0, sizeof(u32), st));
+        for (u32 l = 0; l + 1 < nlev; ++l) {
+            u32* s_cur = startbuf[l & 1];
+            u32* s_next = startbuf[(l + 1) & 1];
+            hipLaunchKernelGGL((down_kernel<u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l].nchild, L[l + 1].sub, s_next);
+            if (L[l + 1].ncand)
+                hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, s_next, L[l + 1].sub, l + 1,
+                                   t_level, t_cidx);
+        }
+        // tuple sizes -> offsets
+        std::vector<LevelDev> lv(nlev);
+        for (u32 l = 0; l < nlev; ++l) {
+            lv[l].parent = L[l].parent; lv[l].sym = L[l].sym; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff;
+            lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = L[l].ncand; lv[l].npairs = L[l].npairs;
+        }
+        LevelDev* d_lv;
+        ARENA_GET(d_lv, LevelDev, nlev);
+        DSM_HIP(hipMemcpyAsync(d_lv, lv.data(), nlev * sizeof(LevelDev), hipMemcpyHostToDevice, st));
+        u32 *plen, *npair, *path_off, *pair_off;
+        ARENA_GET(plen, u32, nt);
+        ARENA_GET(npair, u32, nt);
+        ARENA_GET(path_off, u32, (size_t)nt + 1);
+        ARENA_GET(pair_off, u32, (size_t)nt + 1);
+        hipLaunchKernelGGL(tuple_size_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, plen, npair);
+        u32* stmp;
+        ARENA_GET(stmp, u32, scan_tmp_elems(nt) + 8);
+        exclusive_scan<u32, u32>(plen, path_off, nt, stmp, d_totals, st);
+        exclusive_scan<u32, u32>(npair, pair_off, nt, stmp, d_totals + 1, st);
+        DSM_HIP(hipMemcpyAsync(path_off + nt, d_totals, sizeof(u32), hipMemcpyDeviceToDevice, st));
+        DSM_HIP(hipMemcpyAsync(pair_off + nt, d_totals + 1, sizeof(u32), hipMemcpyDeviceToDevice, st));
+        if (int rc = read_totals(2)) return rc;
+        const u64 path_bytes = h_totals[0], npairs = h_totals[1];
+        char* d_paths;
+        u32* d_ids;
+        u64* d_freqs;
+        ARENA_GET(d_paths, char, path_bytes);
+        ARENA_GET(d_ids, u32, npairs);
+        ARENA_GET(d_freqs, u64, npairs);
+        hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs);
+        DSM_HIP(hipGetLastError());
+        // ---- to the host ------------------------------------------------------------------------
+        std::vector<u32> h_path_off((size_t)nt + 1), h_pair_off((size_t)nt + 1), h_ids(npairs);
+        std::vector<u64> h_freqs(npairs);
+        std::vector<char> h_paths(path_bytes);
+        DSM_HIP(hipMemcpyAsync(h_path_off.data(), path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(h_pair_off.data(), pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(h_ids.data(), d_ids, npairs * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(h_freqs.data(), d_freqs, npairs * 8, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(h_paths.data(), d_paths, path_bytes, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipStreamSynchronize(st));
+        return host_emit(nt, h_path_off, h_paths, h_pair_off, h_ids, h_freqs, sink, ctx);
+    }
+
+    // exact entropy (metaserver.cpp:366-389,413) and delivery, in place
+    int host_emit(u32 nt, std::vector<u32>& path_off, std::vector<char>& paths, std::vector<u32>& pair_off, std::vector<u32>& ids,
+                  std::vector<u64>& freqs, dsm_tuple_sink sink, void* ctx);
+
+    // ---- stream: byte offsets of every token from subtree sizes ------------------------------------
+    int finish_stream(std::vector<LevelHost>& L, u32 nlev, dsm_byte_sink sink, void* ctx) {
+        if (nlev < 2) return 0;  // nothing below the root: the client sends only its handshake
+        const u64 rbase = 0;     // one connection per call: reported starts at 0 (EnumerateQuery.h:19-21)
+        for (u32 l = 0; l < nlev; ++l) {
+            ARENA_GET(L[l].sz, u64, L[l].n);
+            ARENA_GET(L[l].pre, u64, L[l].n);
+            ARENA_GET(L[l].own, u64, L[l].n);
+            ARENA_GET(L[l].bytes, u64, L[l].n);
+            ARENA_GET(L[l].off, u64, L[l].n);
+        }
+        for (u32 l = nlev; l-- > 0;)  // subtree node counts
+            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild, L[l].nchild,
+                               l + 1 < nlev ? L[l + 1].sz : nullptr, L[l].sz);
+        {  // pre-order numbers: pre(child_k) = pre(v) + 1 + sum sz(earlier siblings); root pre = -1
+            u64 m1 = ~0ull;
+            DSM_HIP(hipMemcpyAsync(L[0].pre, &m1, 8, hipMemcpyHostToDevice, st));
+            for (u32 l = 0; l + 1 < nlev; ++l)
+                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l].nchild, L[l + 1].sz,
+                                   L[l + 1].pre);
+        }
+        for (u32 l = 1; l < nlev; ++l)
+            hipLaunchKernelGGL((stream_own_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, (const P*)L[l].freq, L[l].pre, L[l].sz, L[l].own);
+        DSM_HIP(hipMemsetAsync(L[0].own, 0, 8, st));
+        for (u32 l = nlev; l-- > 0;)  // subtree bytes
+            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild, L[l].nchild,
+                               l + 1 < nlev ? L[l + 1].bytes : nullptr, L[l].bytes);
+        {  // byte offsets: off(child_k) = off(v) + 2 + sum bytes(earlier siblings); root off = -2
+            u64 m2 = ~0ull - 1;
+            DSM_HIP(hipMemcpyAsync(L[0].off, &m2, 8, hipMemcpyHostToDevice, st));
+            for (u32 l = 0; l + 1 < nlev; ++l)
+                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l].nchild, L[l + 1].bytes,
+                                   L[l + 1].off);
+        }
+        u64 total = 0;
+        DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipStreamSynchronize(st));
+        u8* d_out;
+        ARENA_GET(d_out, u8, total);
+        for (u32 l = 1; l < nlev; ++l)
+            hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].sym, (const P*)L[l].freq, L[l].left, L[l].pre,
+                               L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
+        DSM_HIP(hipGetLastError());
+        // deliver in pieces through a pinned staging buffer
+        const size_t PIECE = 32u << 20;
+        u8* h_piece = nullptr;
+        DSM_HIP(hipHostMalloc((void**)&h_piece, PIECE));
+        int rc = 0;
+        for (u64 o = 0; o < total && !rc; o += PIECE) {
+            size_t nb = (size_t)((total - o) < PIECE ? (total - o) : PIECE);
+            hipError_t e = hipMemcpyAsync(h_piece, d_out + o, nb, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rc = fail(DSM_E_HIP, hipGetErrorString(e)); break; }
+            if (sink && sink(ctx, h_piece, nb)) rc = fail(DSM_E_SINK, "byte sink failed");
+        }
+        (void)hipHostFree(h_piece);
+        return rc;
+    }
+};
+
+static const double LN2 = 0x1.62e42fefa39efp-1;  // the reference's log(2), folded by its compiler (metaserver.cpp:379,389)
+
+template <typename P>
+int Engine<P>::host_emit(u32 nt, std::vector<u32>& path_off, std::vector<char>& paths, std::vector<u32>& pair_off, std::vector<u32>& ids,
+                         std::vector<u64>& freqs, dsm_tuple_sink sink, void* ctx) {
+    hipEvent_t dummy = nullptr;
+    (void)dummy;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    std::vector<double> ent(nt);
+    std::vector<u8> keep(nt);
+    const double emin = prm.emin, emax = prm.emax;
+    const u64 dd = d;
+    for (long r = 0; r < (long)nt; ++r) {
+        u64 sumN = dd;
+        double sumNlogN = 0;
+        for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
+            u64 f = freqs[q];
+            sumN += f;
+            sumNlogN += (double)(f + 1) * log((double)(f + 1)) / LN2;
+        }
+        double e = log((double)sumN) / LN2 - sumNlogN / (double)sumN;
+        ent[r] = e;
+        keep[r] = !(emax > 0 && (e < emin || e > emax));
+    }
+    // compact in place, order preserved
+    u32 w = 0, pw = 0, qw = 0;
+    std::vector<u32> o_path(1, 0), o_pair(1, 0);
+    o_path.reserve(nt + 1);
+    o_pair.reserve(nt + 1);
+    for (u32 r = 0; r < nt; ++r) {
+        if (!keep[r]) continue;
+        u32 pb = path_off[r], pe = path_off[r + 1], qb = pair_off[r], qe = pair_off[r + 1];
+        if (pw != pb) memmove(&paths[pw], &paths[pb], pe - pb);
+        if (qw != qb) {
+            memmove(&ids[qw], &ids[qb], (qe - qb) * 4);
+            memmove(&freqs[qw], &freqs[qb], (qe - qb) * 8);
+        }
+        pw += pe - pb;
+        qw += qe - qb;
+        ent[w++] = ent[r];
+        o_path.push_back(pw);
+        o_pair.push_back(qw);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    stats.host_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    stats.tuples += w;
+    stats.pairs += qw;
+    if (w && sink) {
+        dsm_tuple_batch b;
+        b.ntuples = w;
+        b.path_off = o_path.data();
+        b.path_bytes = paths.data();
+        b.entropy = ent.data();
+        b.pair_off = o_pair.data();
+        b.ids = ids.data();
+        b.freqs = freqs.data();
+        if (sink(ctx, &b)) return fail(DSM_E_SINK, "tuple sink failed");
+    }
+    return 0;
+}
+
+static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
+    if (p && p->wide) return true;
+    for (int k = 0; k < n; ++k)
+        if (idx[k]->meta.n >= 0xFFFFFFF0ull) return true;
+    return false;
+}
+
+struct MinerBase {
+    virtual ~MinerBase() {}
+    virtual int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
+};
+template <typename P>
+struct MinerT : MinerBase {
+    Engine<P> e;
+    int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
+        memset(&e.stats, 0, sizeof e.stats);
+        int rc = e.run(prefix, ts, bs, ctx);
+        if (out) *out = e.stats;
+        return rc;
+    }
+};
+
+template <typename P>
+static int mine_impl(dsm_index* const* idx, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    std::unique_ptr<Engine<P>> e(new Engine<P>());
+    int rc = e->init(idx, n, *p, false);
+    if (!rc) rc = e->run(p->prefix, sink, nullptr, ctx);
+    if (stats) *stats = e->stats;
+    return rc;
+}
+template <typename P>
+static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 maxdepth, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
+    dsm_params p;
+    dsm_params_default(&p);
+    p.prefix = prefix;
+    p.fmin = fmin;
+    p.maxdepth = maxdepth;
+    std::unique_ptr<Engine<P>> e(new Engine<P>());
+    dsm_index* one = const_cast<dsm_index*>(idx);
+    int rc = e->init(&one, 1, p, true);
+    if (!rc) rc = e->run(prefix, nullptr, sink, ctx);
+    if (stats) *stats = e->stats;
+    return rc;
+}
+
+}  // namespace dsm
+
+using namespace dsm;
+
+extern "C" {
+
+void dsm_params_default(dsm_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->prefix = "";
+    p->fmin = 10;            // metaenumerate.cpp:141
+    p->maxdepth = ~0u;       // metaenumerate.cpp:142
+    p->pmin = 2;             // metaserver.cpp:126
+    p->pmax = 0;
+    p->mindepth = 0;
+    p->emin = 0.0;
+    p->emax = -1.0;          // mandatory in the reference CLI (metaserver.cpp:582-586)
+    p->world_size = 1;
+}
+
+int dsm_enumerate(const dsm_index* idx, const char* prefix, uint32_t fmin, uint32_t maxdepth, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
+    if (!idx) return fail(DSM_E_INVAL, "dsm_enumerate: null index");
+    dsm_index* one = const_cast<dsm_index*>(idx);
+    if (need_wide(&one, 1, nullptr)) return enum_impl<u64>(idx, prefix, fmin, maxdepth, sink, ctx, stats);
+    return enum_impl<u32>(idx, prefix, fmin, maxdepth, sink, ctx, stats);
+}
+
+int dsm_mine(dsm_index* const* idx, int nlocal, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    if (!idx || nlocal <= 0 || !p) return fail(DSM_E_INVAL, "dsm_mine: bad arguments");
+    for (int k = 0; k < nlocal; ++k)
+        if (!idx[k]) return fail(DSM_E_INVAL, "dsm_mine: null index");
+    if (need_wide(idx, nlocal, p)) return mine_impl<u64>(idx, nlocal, p, sink, ctx, stats);
+    return mine_impl<u32>(idx, nlocal, p, sink, ctx, stats);
+}
+
+int dsm_miner_create(dsm_index* const* idx, int nlocal, const dsm_params* p, int stream_mode, dsm_miner** out) {
+    if (!idx || nlocal <= 0 || !p || !out) return fail(DSM_E_INVAL, "dsm_miner_create: bad arguments");
+    for (int k = 0; k < nlocal; ++k)
+        if (!idx[k]) return fail(DSM_E_INVAL, "dsm_miner_create: null index");
+    if (stream_mode && (nlocal != 1 || p->world_size > 1)) return fail(DSM_E_INVAL, "stream mode takes exactly one local index");
+    *out = nullptr;
+    int rc;
+    MinerBase* m;
+    if (need_wide(idx, nlocal, p)) { auto* t = new MinerT<u64>(); rc = t->e.init(idx, nlocal, *p, stream_mode != 0); m = t; }
+    else { auto* t = new MinerT<u32>(); rc = t->e.init(idx, nlocal, *p, stream_mode != 0); m = t; }
+    if (rc) { delete m; return rc; }
+    *out = reinterpret_cast<dsm_miner*>(m);
+    return DSM_OK;
+}
+int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    if (!m) return fail(DSM_E_INVAL, "null miner");
+    return reinterpret_cast<MinerBase*>(m)->run(prefix, sink, nullptr, ctx, stats);
+}
+int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
+    if (!m) return fail(DSM_E_INVAL, "null miner");
+    return reinterpret_cast<MinerBase*>(m)->run(prefix, nullptr, sink, ctx, stats);
+}
+void dsm_miner_destroy(dsm_miner* m) { delete reinterpret_cast<MinerBase*>(m); }
+
+int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // metaserver.cpp:472-484
+    if (!b || !text || !len) return fail(DSM_E_INVAL, "dsm_format_batch: null argument");
+    size_t cap = 64;
+    for (u64 r = 0; r < b->ntuples; ++r)
+        cap += (b->path_off[r + 1] - b->path_off[r]) + 48 + (size_t)(b->pair_off[r + 1] - b->pair_off[r]) * 34;
+    char* out = (char*)malloc(cap);
+    if (!out) return fail(DSM_E_NOMEM, "malloc failed");
+    size_t w = 0;
+    for (u64 r = 0; r < b->ntuples; ++r) {
+        size_t pl = b->path_off[r + 1] - b->path_off[r];
+        memcpy(out + w, b->path_bytes + b->path_off[r], pl);
+        w += pl;
+        w += (size_t)snprintf(out + w, cap - w, " %f", b->entropy[r]);
+        for (u32 q = b->pair_off[r]; q < b->pair_off[r + 1]; ++q)
+            w += (size_t)snprintf(out + w, cap - w, " %d:%lu", (int)b->ids[q], (unsigned long)b->freqs[q]);
+        out[w++] = '\n';
+    }
+    out[w] = 0;
+    *text = out;
+    *len = w;
+    return DSM_OK;
+}
+
+}  // extern "C"

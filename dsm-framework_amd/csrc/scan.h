@@ -1,0 +1,106 @@
+// scan.h -- device-wide exclusive prefix sum (reduce / scan-of-sums / downsweep), wave64 shuffles.
+// Used for frontier compaction, candidate offsets and the per-block symbol counts of the index.
+#pragma once
+#include "common.h"
+
+namespace dsm {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns exclusive prefix, total in *tot
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* tot) {
+    __shared__ T wsum[SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T inc = wave_inclusive_scan(v);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    T base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) {
+        T s = wsum[k];
+        if (k < w) base += s;
+        total += s;
+    }
+    __syncthreads();
+    *tot = total;
+    return base + inc - v;
+}
+
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const InT* __restrict__ in, size_t n, OutT* __restrict__ sums) {
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    OutT s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += (OutT)in[base + k];
+    OutT tot;
+    block_exclusive_scan<OutT>(s, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// out[i] = offsets[block] + exclusive prefix inside the tile.  in/out may alias.
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const InT* in, OutT* out, size_t n, const OutT* __restrict__ offsets,
+                                                                OutT* __restrict__ total) {
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    OutT v[SCAN_ITEMS];
+    OutT s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? (OutT)in[base + k] : (OutT)0;
+        s += v[k];
+    }
+    OutT tot;
+    OutT ex = block_exclusive_scan<OutT>(s, &tot);
+    OutT off = offsets ? offsets[blockIdx.x] : (OutT)0;
+    ex += off;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + tot;
+}
+
+inline size_t scan_tmp_elems(size_t n) {
+    size_t t = 0;
+    while (n > (size_t)SCAN_TILE) {
+        n = (n + SCAN_TILE - 1) / SCAN_TILE;
+        t += n;
+    }
+    return t + 1;
+}
+
+// Exclusive scan of in[0..n) into out[0..n) (may alias when InT == OutT); grand total to *d_total (device, may be null).
+// tmp must hold scan_tmp_elems(n) OutT values.
+template <typename InT, typename OutT>
+inline void exclusive_scan(const InT* in, OutT* out, size_t n, OutT* tmp, OutT* d_total, hipStream_t st) {
+    if (n == 0) {
+        if (d_total) hipMemsetAsync(d_total, 0, sizeof(OutT), st);
+        return;
+    }
+    size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb == 1) {
+        hipLaunchKernelGGL((scan_down_kernel<InT, OutT>), dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)nullptr, d_total);
+        return;
+    }
+    hipLaunchKernelGGL((scan_reduce_kernel<InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
+    exclusive_scan<OutT, OutT>(tmp, tmp, nb, tmp + nb, d_total, st);
+    hipLaunchKernelGGL((scan_down_kernel<InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);
+}
+
+}  // namespace dsm

@@ -1,0 +1,302 @@
+"""pydsm -- thin ctypes binding of libdsmhip.so (include/dsmhip.h).
+
+Host-side mirror of the reference's interfaces for the substring-enumeration path:
+  Index            ~ TextCollection::load / FMIndex (LF, getL, getLength)      FMIndex.h:68-102
+  Index.enumerate  ~ EnumerateQuery::enumerate + ClientSocket encoders         EnumerateQuery.cpp:9-290
+  mine             ~ all clients + metaserver traverse() for one prefix        metaserver.cpp:269-486
+There is no CPU fallback: every call runs HIP kernels and raises DsmError when the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdsmhip.so")
+
+LAYOUT_PLANES = 0
+LAYOUT_WT = 1
+OPEN_KEEP_WT = 1
+MAXDEPTH_NONE = 0xFFFFFFFF
+
+
+class DsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dsmhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Code(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("bits", C.c_uint32), ("code", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("reported", C.c_uint64), ("lf_steps", C.c_uint64), ("rank_ops", C.c_uint64), ("union_nodes", C.c_uint64),
+                ("tuples", C.c_uint64), ("pairs", C.c_uint64), ("candidates", C.c_uint64), ("levels", C.c_uint64),
+                ("max_frontier", C.c_uint64), ("expand_launches", C.c_uint64), ("expand_ms", C.c_double),
+                ("device_ms", C.c_double), ("host_ms", C.c_double), ("pair_order_exact", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TupleBatch(C.Structure):
+    _fields_ = [("ntuples", C.c_uint64), ("path_off", C.POINTER(C.c_uint32)), ("path_bytes", C.c_void_p),
+                ("entropy", C.POINTER(C.c_double)), ("pair_off", C.POINTER(C.c_uint32)), ("ids", C.POINTER(C.c_uint32)),
+                ("freqs", C.POINTER(C.c_uint64))]
+
+
+BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+TUPLE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TupleBatch))
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Params(C.Structure):
+    _fields_ = [("prefix", C.c_char_p), ("fmin", C.c_uint32), ("maxdepth", C.c_uint32), ("pmin", C.c_uint32),
+                ("pmax", C.c_uint32), ("mindepth", C.c_uint32), ("emin", C.c_double), ("emax", C.c_double),
+                ("world_size", C.c_uint32), ("rank", C.c_uint32), ("allgather", ALLGATHER), ("allgather_ctx", C.c_void_p),
+                ("exchange_send", C.c_void_p), ("exchange_recv", C.c_void_p), ("exchange_bytes", C.c_uint64),
+                ("arena_bytes", C.c_uint64), ("wide", C.c_uint32), ("stream", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libdsmhip.so (fails loudly if it was not built: `make -C dsm-framework_amd`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DsmError(-2, "libdsmhip.so not built (run `make -C dsm-framework_amd` or __graft_entry__.build())")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+        # Importing torch first makes libdsmhip.so bind to the copy torch uses, so device pointers, streams
+        # and torch.distributed (RCCL) all live in the same runtime.  torch is plumbing here, not compute.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.dsm_last_error.restype = C.c_char_p
+        L.dsm_abi_version.restype = C.c_int
+        L.dsm_index_open_ex.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+        L.dsm_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_index_close.argtypes = [C.c_void_p]
+        L.dsm_index_length.restype = C.c_uint64
+        L.dsm_index_length.argtypes = [C.c_void_p]
+        L.dsm_index_meta.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dsm_index_name.restype = C.c_char_p
+        L.dsm_index_name.argtypes = [C.c_void_p]
+        L.dsm_index_device.argtypes = [C.c_void_p]
+        L.dsm_index_device_bytes.restype = C.c_uint64
+        L.dsm_index_device_bytes.argtypes = [C.c_void_p]
+        L.dsm_lf_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dsm_lf_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]
+        L.dsm_getl_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dsm_index_check.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.dsm_enumerate.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_params_default.argtypes = [C.POINTER(Params)]
+        L.dsm_mine.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_miner_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_miner_mine.argtypes = [C.c_void_p, C.c_char_p, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_miner_enumerate.argtypes = [C.c_void_p, C.c_char_p, BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_miner_destroy.argtypes = [C.c_void_p]
+        L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.dsm_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DsmError(rc, lib().dsm_last_error().decode(errors="replace"))
+
+
+class Index:
+    """HBM-resident FM-index opened from a reference-format .fmi file."""
+
+    def __init__(self, path, device=0, keep_wt=False):
+        self.h = C.c_void_p()
+        _check(lib().dsm_index_open_ex(os.fsencode(path), device, OPEN_KEEP_WT if keep_wt else 0, C.byref(self.h)))
+        self.n = lib().dsm_index_length(self.h)
+        self.name = lib().dsm_index_name(self.h).decode()
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().dsm_index_close(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def meta(self):
+        Cc = np.zeros(256, np.uint64)
+        codes = (Code * 256)()
+        _check(lib().dsm_index_meta(self.h, Cc.ctypes.data, codes))
+        return Cc, codes
+
+    def device_bytes(self):
+        return lib().dsm_index_device_bytes(self.h)
+
+    def lf_batch(self, c, i):
+        """LF(c[k], i[k]) for host arrays (FMIndex.h:84-90)."""
+        c = np.ascontiguousarray(c, np.uint8)
+        i = np.ascontiguousarray(i, np.uint64)
+        out = np.zeros(len(c), np.uint64)
+        _check(lib().dsm_lf_batch(self.h, c.ctypes.data, i.ctypes.data, out.ctypes.data, len(c), None))
+        return out
+
+    def lf_batch_dev(self, d_c, d_i, d_out, k, layout=LAYOUT_PLANES, stream=None):
+        _check(lib().dsm_lf_batch_dev(self.h, d_c, d_i, d_out, k, layout, stream))
+
+    def getl_batch(self, i):
+        i = np.ascontiguousarray(i, np.uint64)
+        out = np.zeros(len(i), np.uint8)
+        _check(lib().dsm_getl_batch(self.h, i.ctypes.data, out.ctypes.data, len(i), None))
+        return out
+
+    def check(self):
+        """metaenumerate --check (metaenumerate.cpp:93-127): returns the interval-size total; == n when sane."""
+        t = C.c_uint64(0)
+        _check(lib().dsm_index_check(self.h, C.byref(t)))
+        return t.value
+
+    def enumerate(self, prefix, fmin=10, maxdepth=MAXDEPTH_NONE, with_header=True):
+        """Wire bytes of one client connection: b'S' name b'.' + node grammar (EnumerateQuery.cpp).  -> (bytes, stats)"""
+        chunks = []
+
+        def sink(ctx, p, n):
+            chunks.append(C.string_at(p, n))
+            return 0
+
+        cb = BYTE_SINK(sink)
+        st = Stats()
+        _check(lib().dsm_enumerate(self.h, prefix.encode(), fmin, maxdepth, cb, None, C.byref(st)))
+        body = b"".join(chunks)
+        if with_header:
+            body = b"S" + self.name.encode() + b"." + body  # metaenumerate.cpp:285-286
+        return body, st
+
+
+def default_params():
+    p = Params()
+    lib().dsm_params_default(C.byref(p))
+    return p
+
+
+def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes, wide,
+                 stream, keep):
+    p = default_params()
+    p.fmin, p.maxdepth, p.pmin, p.pmax, p.mindepth = fmin, maxdepth, pmin, pmax, mindepth
+    p.emin, p.emax = emin, emax
+    p.world_size, p.rank = world_size, rank
+    p.arena_bytes = arena_bytes
+    p.wide = wide
+    p.stream = stream
+    if allgather is not None:
+        def _ag(ctx, s, r, n, st):
+            try:
+                allgather(s, r, n, st)
+                return 0
+            except Exception:  # noqa: BLE001 - must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb_ag = ALLGATHER(_ag)
+        keep.append(cb_ag)
+        p.allgather = cb_ag
+    if exchange is not None:
+        p.exchange_send, p.exchange_recv, p.exchange_bytes = exchange
+    return p
+
+
+def _tuple_sink(out, text, on_batch):
+    def sink(ctx, b):
+        if on_batch is not None:
+            on_batch(b.contents)
+        if text:
+            t = C.c_void_p()
+            n = C.c_size_t(0)
+            if lib().dsm_format_batch(b, C.byref(t), C.byref(n)) != 0:
+                return 1
+            out.append(C.string_at(t, n.value))
+            lib().dsm_free(t)
+        return 0
+    return TUPLE_SINK(sink)
+
+
+class Miner:
+    """Persistent enumeration state over a fixed set of local indexes (device buffers allocated once).
+
+    stream_mode=False: .mine(prefix) -> (tuple text, Stats);  stream_mode=True (one index): .enumerate(prefix)."""
+
+    def __init__(self, indexes, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0,
+                 world_size=1, rank=0, allgather=None, exchange=None, arena_bytes=0, wide=0, stream=None, stream_mode=False):
+        self._keep = []
+        self.indexes = list(indexes)
+        p = _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes,
+                         wide, stream, self._keep)
+        hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
+        self.h = C.c_void_p()
+        _check(lib().dsm_miner_create(hs, len(indexes), C.byref(p), 1 if stream_mode else 0, C.byref(self.h)))
+
+    def mine(self, prefix, text=True, on_batch=None):
+        out = []
+        cb = _tuple_sink(out, text, on_batch)
+        st = Stats()
+        _check(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)))
+        return (b"".join(out) if text else None), st
+
+    def enumerate(self, prefix, with_header=True, discard=False):
+        chunks = []
+        nbytes = [0]
+
+        def sink(ctx, p, n):
+            nbytes[0] += n
+            if not discard:
+                chunks.append(C.string_at(p, n))
+            return 0
+
+        cb = BYTE_SINK(sink)
+        st = Stats()
+        _check(lib().dsm_miner_enumerate(self.h, prefix.encode(), cb, None, C.byref(st)))
+        if discard:
+            return nbytes[0], st
+        body = b"".join(chunks)
+        if with_header:
+            body = b"S" + self.indexes[0].name.encode() + b"." + body
+        return body, st
+
+    def close(self):
+        if self.h:
+            lib().dsm_miner_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def mine(indexes, prefix, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0,
+         world_size=1, rank=0, allgather=None, exchange=None, arena_bytes=0, wide=0, stream=None, text=True,
+         on_batch=None):
+    """Enumerate + merge + entropy filter for one prefix over the local indexes (collective when world_size > 1).
+
+    Returns (metaserver-format text bytes or None, Stats).  `allgather(send_ptr, recv_ptr, nbytes, stream)` is
+    called once per frontier level when world_size > 1.  `exchange` = (send_ptr, recv_ptr, nbytes) lets the caller
+    own the exchange buffers (e.g. torch tensors handed to torch.distributed)."""
+    keep = []
+    p = _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes, wide,
+                     stream, keep)
+    p.prefix = prefix.encode()
+    out = []
+    cb = _tuple_sink(out, text, on_batch)
+    hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
+    st = Stats()
+    _check(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)))
+    return (b"".join(out) if text else None), st

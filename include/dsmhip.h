@@ -1,0 +1,187 @@
+/* dsmhip.h -- C ABI of libdsmhip.so: the MI355X-native substring-enumeration hot path of the
+ * Distributed String Mining framework (FM-index LF-mapping enumeration + cross-sample merge).
+ *
+ * The reference has no FFI; the path sits behind (1) the .fmi v17 file, (2) the C++ virtual
+ * TextCollection interface, (3) the client->server wire protocol, (4) metaserver's stdout.
+ * Every entry point below names the reference interface it replaces (paths relative to the
+ * reference tree).  No C++ or torch type crosses this boundary: plain pointers and sizes only.
+ *
+ * Conventions
+ *   - return value 0 = success, negative = -errno style failure; dsm_last_error() (thread local)
+ *     has the message.  The library never exits the process (the reference CLIs exit(1)/abort();
+ *     that behaviour belongs to the CLI wrappers, not the library).
+ *   - handles are immutable after open; query entry points are re-entrant.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - a GPU is mandatory: there is no CPU fallback anywhere behind this header.
+ */
+#ifndef DSMHIP_H_
+#define DSMHIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_ABI_VERSION 1
+
+/* error codes (negative errno values) */
+#define DSM_OK 0
+#define DSM_E_INVAL (-22)      /* bad argument */
+#define DSM_E_NOENT (-2)       /* file not found */
+#define DSM_E_IO (-5)          /* truncated / unreadable file */
+#define DSM_E_FORMAT (-74)     /* not a .fmi v14..v17 (reference throws std::runtime_error, FMIndex.cpp:267-268) */
+#define DSM_E_NOMEM (-12)
+#define DSM_E_NODEV (-19)      /* no usable HIP device */
+#define DSM_E_UNSUPPORTED (-95)
+#define DSM_E_CAPACITY (-28)   /* a frontier level does not fit the arena: use a longer prefix or a larger arena */
+#define DSM_E_HIP (-71)        /* a HIP runtime call or kernel failed */
+#define DSM_E_SINK (-125)      /* the caller's sink returned non-zero */
+
+const char* dsm_last_error(void);
+int dsm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index object.  Replaces TextCollection::load + class FMIndex (TextCollection.cpp:27-62,
+ * FMIndex.cpp:245-357): reads a .fmi written by the unmodified reference builder and makes it
+ * resident in HBM in the device layout (DESIGN.md "Data layout").
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsm_index dsm_index;
+
+/* HuffWT::TCodeEntry, HuffWT.h:13-46 */
+typedef struct dsm_code {
+    uint64_t count;
+    uint32_t bits;
+    uint32_t code;
+} dsm_code;
+
+#define DSM_OPEN_KEEP_WT 1u /* keep the file's Huffman wavelet tree (reference 3-array layout) in HBM too */
+
+int dsm_index_open(const char* fmi_path, int device, dsm_index** out);
+int dsm_index_open_ex(const char* fmi_path, int device, unsigned flags, dsm_index** out);
+void dsm_index_close(dsm_index* idx);
+/* TextCollection::getLength(), FMIndex.h:68-69 */
+uint64_t dsm_index_length(const dsm_index* idx);
+/* C[] of FMIndex.h:84-90 and the Huffman code table of HuffWT.h:49-54 */
+int dsm_index_meta(const dsm_index* idx, uint64_t C[256], dsm_code codes[256]);
+/* sample name the server sees: basename up to the first '.', metaenumerate.cpp:79-88 */
+const char* dsm_index_name(const dsm_index* idx);
+int dsm_index_device(const dsm_index* idx);
+/* bytes of HBM held by the handle */
+uint64_t dsm_index_device_bytes(const dsm_index* idx);
+
+/* LF(c,i) = C[c] + rank_c(BWT, i) -- TextCollection::LF, FMIndex.h:84-90 (HuffWT::rank HuffWT.h:66-83,
+ * BitRank::rank BitRank.cpp:191-195).  i = UINT64_MAX is legal (rank(-1) = 0).  Host pointers. */
+int dsm_lf_batch(const dsm_index* idx, const uint8_t* c, const uint64_t* i, uint64_t* out, size_t k, void* stream);
+/* Same on device-resident arrays, asynchronous on `stream`.
+ * layout: DSM_LAYOUT_PLANES = interleaved bit-plane blocks (the enumeration layout);
+ *         DSM_LAYOUT_WT     = the file's wavelet tree walked node by node (needs DSM_OPEN_KEEP_WT). */
+#define DSM_LAYOUT_PLANES 0u
+#define DSM_LAYOUT_WT 1u
+int dsm_lf_batch_dev(const dsm_index* idx, const uint8_t* d_c, const uint64_t* d_i, uint64_t* d_out, size_t k,
+                     unsigned layout, void* stream);
+/* getL(i) = BWT[i] -- TextCollection::getL, FMIndex.h:99-102.  Host pointers. */
+int dsm_getl_batch(const dsm_index* idx, const uint64_t* i, uint8_t* out, size_t k, void* stream);
+/* metaenumerate --check (metaenumerate.cpp:93-127): sum over c of |LF-interval(c)|; *total == n when sane. */
+int dsm_index_check(const dsm_index* idx, uint64_t* total);
+
+/* ------------------------------------------------------------------------------------------------
+ * Counters every enumeration exports: work as the REFERENCE would have executed it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsm_stats {
+    uint64_t reported;       /* emitted trie nodes = '(' tokens (EnumerateQuery.cpp:209), summed over local samples */
+    uint64_t lf_steps;       /* TextCollection::LF calls the reference would make */
+    uint64_t rank_ops;       /* BitRank::rank calls the reference would make (17 algorithmic bytes each) */
+    uint64_t union_nodes;    /* merged trie nodes (metaserver total_paths) */
+    uint64_t tuples;         /* printed tuples (metaserver total_output) */
+    uint64_t pairs;          /* printed id:freq pairs (metaserver total_occs) */
+    uint64_t candidates;     /* tuples handed to the host for the exact entropy test */
+    uint64_t levels;         /* frontier levels processed */
+    uint64_t max_frontier;   /* widest level */
+    uint64_t expand_launches;
+    double expand_ms;        /* HIP-event time summed over expand (LF-step) kernel launches */
+    double device_ms;        /* HIP-event time of everything enqueued for the call */
+    double host_ms;          /* host post-processing (exact entropy, tuple assembly) */
+    uint64_t pair_order_exact; /* 1 when id:freq order and FP summation order follow the reference bit for bit */
+} dsm_stats;
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-sample enumeration.  Replaces EnumerateQuery::enumerate (EnumerateQuery.cpp:9-290) plus the
+ * ClientSocket encoders (ClientSocket.h:12-46): the sink receives the exact bytes the reference client
+ * writes to its socket AFTER the 'S' name '.' handshake, i.e. the node grammar
+ *     node := '(' sym node* varint(freq) ['R' varint(count)]{depth<=6} leftchar ')'
+ * in stream order, in one or more consecutive pieces.
+ * ---------------------------------------------------------------------------------------------- */
+typedef int (*dsm_byte_sink)(void* ctx, const uint8_t* bytes, size_t n);
+
+int dsm_enumerate(const dsm_index* idx, const char* prefix, uint32_t fmin, uint32_t maxdepth,
+                  dsm_byte_sink sink, void* ctx, dsm_stats* stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-sample mining = enumerate + merge + entropy filter.  Replaces, for one prefix, every client's
+ * EnumerateQuery plus metaserver's traverse() (metaserver.cpp:269-486).  Collective across ranks.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsm_tuple_batch {
+    uint64_t ntuples;
+    const uint32_t* path_off;  /* ntuples+1 offsets into path_bytes */
+    const char* path_bytes;    /* substrings, A/C/G/T, not NUL terminated */
+    const double* entropy;     /* exactly metaserver.cpp:389 (host double, glibc log) */
+    const uint32_t* pair_off;  /* ntuples+1 offsets into ids/freqs */
+    const uint32_t* ids;       /* sample ids in the reference's print order */
+    const uint64_t* freqs;
+} dsm_tuple_batch;
+
+/* Receives tuples in the reference's output order (post-order, metaserver.cpp:467-485). */
+typedef int (*dsm_tuple_sink)(void* ctx, const dsm_tuple_batch* batch);
+
+/* One exchange per frontier level: every rank contributes bytes_per_rank bytes at sendbuf and must end
+ * up with world_size * bytes_per_rank bytes at recvbuf, rank-major (ncclAllGather semantics).  Device
+ * pointers; must be ordered after prior work on `stream` and before later work on it. */
+typedef int (*dsm_allgather_fn)(void* ctx, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
+
+typedef struct dsm_params {
+    const char* prefix;      /* enforced path (hostinfo third column, metaenumerate.cpp:216); "" = whole trie */
+    uint32_t fmin;           /* metaenumerate --fmin (default 10, metaenumerate.cpp:141) */
+    uint32_t maxdepth;       /* metaenumerate --maxdepth (default ~0u) */
+    uint32_t pmin;           /* metaserver -P (default 2, metaserver.cpp:126) */
+    uint32_t pmax;           /* metaserver --pmax (0 = no limit) */
+    uint32_t mindepth;       /* metaserver -m */
+    double emin;             /* metaserver -e */
+    double emax;             /* metaserver -E (mandatory there; <= 0 disables the entropy test, metaserver.cpp:413) */
+    /* distribution: sample id of local index j is rank*nlocal + j; all ranks pass the same nlocal */
+    uint32_t world_size;     /* 0 or 1 = single process */
+    uint32_t rank;
+    dsm_allgather_fn allgather;
+    void* allgather_ctx;
+    void* exchange_send;     /* optional caller-owned device buffers (e.g. torch tensors) of exchange_bytes */
+    void* exchange_recv;     /*   recv must hold world_size * exchange_bytes */
+    uint64_t exchange_bytes;
+    uint64_t arena_bytes;    /* device scratch budget; 0 = pick from free memory */
+    uint32_t wide;           /* 1 = force 64-bit positions (all ranks must agree); 0 = from local index sizes */
+    void* stream;
+} dsm_params;
+
+void dsm_params_default(dsm_params* p);
+
+int dsm_mine(dsm_index* const* idx, int nlocal, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
+
+/* Persistent form of the two calls above: device buffers are allocated once and reused for every
+ * prefix (the reference keeps one EnumerateQuery + socket per prefix alive for the whole run,
+ * metaenumerate.cpp:268-309).  p->prefix is ignored at creation; fmin/maxdepth/pmin/... are fixed.
+ * stream_mode != 0: single local index, dsm_miner_enumerate delivers wire bytes;
+ * stream_mode == 0: dsm_miner_mine delivers tuples. */
+typedef struct dsm_miner dsm_miner;
+int dsm_miner_create(dsm_index* const* idx, int nlocal, const dsm_params* p, int stream_mode, dsm_miner** out);
+int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
+int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats);
+void dsm_miner_destroy(dsm_miner* m);
+
+/* metaserver's printf formatting of a batch (metaserver.cpp:472-484): "path %f id:freq ...\n".
+ * *text is malloc'd; release with dsm_free. */
+int dsm_format_batch(const dsm_tuple_batch* batch, char** text, size_t* len);
+void dsm_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSMHIP_H_ */

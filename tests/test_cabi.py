@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/dsmhip.h declares, and refuses to work without a GPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "dsmhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(dsm_[a-z_0-9]+)\s*\(", hdr))
+    names -= {"dsm_byte_sink", "dsm_tuple_sink", "dsm_allgather_fn"}
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    import pydsm
+    L = pydsm.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "libdsmhip.so does not export " + s
+    assert L.dsm_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import pydsm
+    p = pydsm.default_params()
+    assert (p.fmin, p.pmin, p.pmax, p.maxdepth, p.world_size) == (10, 2, 0, 0xFFFFFFFF, 1)
+    assert p.emax == -1.0 and p.emin == 0.0
+    assert C.sizeof(pydsm.Code) == 16
+    assert C.sizeof(pydsm.Stats) == 14 * 8
+
+
+def test_no_cpu_fallback_without_gpu(golden):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pydsm
+    with pytest.raises(pydsm.DsmError) as e:
+        pydsm.Index(golden.fmi("toy3", "toy-1"))
+    assert e.value.code == -19  # DSM_E_NODEV
+
+
+def test_open_errors_are_reported_not_fatal(tmp_path):
+    import pydsm
+    with pytest.raises(pydsm.DsmError):
+        pydsm.Index(str(tmp_path / "missing.fmi"))
