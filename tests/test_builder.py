@@ -1,0 +1,96 @@
+"""Own .fmi writer (data preparation for the benchmark configurations) against the reference builder:
+same BWT, same header fields, and -- when oracle/_ref is present -- the unmodified reference
+metaenumerate reads our file and emits the same streams."""
+import os
+import socket
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.fixture(scope="module")
+def builder():
+    from pydsm import builder as b
+    return b
+
+
+@pytest.mark.parametrize("setname,name", [("toy3", "toy-2"), ("toyN", "toyN"), ("five", "five-1")])
+def test_same_bwt_and_tables_as_reference_builder(golden, builder, tmp_path, setname, name):
+    out = str(tmp_path / (name + ".fasta.fmi"))
+    info = builder.build_from_fasta(golden.fasta(setname, name), out)
+    ref = orc.Index(golden.fmi(setname, name))
+    own = orc.Index(out)
+    assert own.n == ref.n == info["n"]
+    assert (own.bwt() == ref.bwt()).all()
+    for a, b in zip(own.meta(), ref.meta()):
+        assert (a == b).all()
+    # Huffman tie order follows libstdc++'s heap, so the file itself is byte-identical
+    assert open(out, "rb").read() == open(golden.fmi(setname, name), "rb").read()
+    # and the oracle enumerates the same stream from either file
+    s1, _ = own.enumerate(name, "AC", fmin=2)
+    s2, _ = ref.enumerate(name, "AC", fmin=2)
+    assert s1 == s2
+    own.close()
+    ref.close()
+
+
+def test_codes_path_equals_fasta_path(builder, tmp_path):
+    codes = builder.synth_reads(seed=7, nreads=300, rlen=40, genome_len=2000, sub_rate=0.01)
+    a = str(tmp_path / "a.fmi")
+    b = str(tmp_path / "b.fmi")
+    builder.build_from_codes(codes, a)
+    builder.build_from_fasta(builder.codes_to_fasta(codes), b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # synthetic sets are seeded: same seed, same reads; samples share the genome
+    again = builder.synth_reads(seed=7, nreads=300, rlen=40, genome_len=2000, sub_rate=0.01)
+    assert torch.equal(codes, again)
+
+
+def test_variable_length_and_edge_reads(builder, tmp_path):
+    fasta = ">a\nACGTNNAC\n>b\nA\n>c\nacgtRYacgtacgtacgtt\n>d\nTTTTTTTTTTTT\n>e\nTTTTTTTTTTTT\n"
+    out = str(tmp_path / "v.fasta.fmi")
+    builder.build_from_fasta(fasta, out)
+    if os.path.exists(os.path.join(REF, "builder")):
+        fa = tmp_path / "r.fasta"
+        fa.write_text(fasta)
+        subprocess.run([os.path.join(REF, "builder"), str(fa)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert open(out, "rb").read() == open(str(fa) + ".fmi", "rb").read()
+    ix = orc.Index(out)
+    assert ix.n == sum(2 * len(r) + 2 for r in ["ACGTNNAC", "A", "acgtRYacgtacgtacgtt", "T" * 12, "T" * 12])
+    ix.close()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "metaenumerate")), reason="needs oracle/_ref (build container only)")
+def test_reference_client_reads_our_file(golden, builder, tmp_path):
+    name = "toy-3"
+    out = str(tmp_path / (name + ".fasta.fmi"))
+    builder.build_from_fasta(golden.fasta("toy3", name), out)
+    srv = socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    got = []
+
+    def sink():
+        c, _ = srv.accept()
+        buf = []
+        while True:
+            b = c.recv(1 << 16)
+            if not b:
+                break
+            buf.append(b)
+        got.append(b"".join(buf))
+
+    t = threading.Thread(target=sink)
+    t.start()
+    subprocess.run([os.path.join(REF, "metaenumerate"), "--fmin", "2", out], input=("127.0.0.1 %d GT\n" % srv.getsockname()[1]).encode(),
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t.join()
+    assert got[0] == golden.stream("toy3", name, "GT")
