@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- enumerated substrings/s of the MI355X substring-enumeration hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] at N=1, configs[2] at N>1): one synthetic read set per GPU,
+10^7 reads x 100 bp from a shared 50 Mbp random genome (20x, 0.5 % substitutions; seeds 42+rank), indexed as
+the reference builder would (n = 2.02e9 BWT symbols, .fmi v17 written by pydsm.builder and loaded through
+the C ABI), enumerated with --fmin 10, merged and filtered with -E 2.0 (-P 1 for a single sample, the reference
+default -P 2 otherwise).  A step = one pass of enumerate+merge+filter over every k-mer prefix for every sample.
+Index construction and loading are outside the timed region; inputs are HBM resident when it starts.
+
+One JSON line on rank 0; `value` = emitted trie nodes ('(' tokens, EnumerateQuery.cpp:209) summed over all
+samples and steps / max-over-ranks wall time.
+"""
+import argparse
+import ctypes
+import itertools
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_RANK = 17    # 8 B superblock + 1 B block + 8 B word per BitRank::rank
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--rlen", type=int, default=100)
+    ap.add_argument("--genome", type=int, default=50_000_000)
+    ap.add_argument("--sub-rate", type=float, default=0.005)
+    ap.add_argument("--prefix-len", type=int, default=1)
+    ap.add_argument("--fmin", type=int, default=10)
+    ap.add_argument("--emax", type=float, default=2.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
+    return ap.parse_args()
+
+
+def build_index(args, rank, dev):
+    import torch
+    from pydsm import builder
+    os.makedirs(args.workdir, exist_ok=True)
+    tag = "s%d_r%d_l%d_g%d_e%g" % (42 + rank, args.reads, args.rlen, args.genome, args.sub_rate)
+    path = os.path.join(args.workdir, "sample-%d.%s.fmi" % (rank, tag))
+    t0 = time.time()
+    if not os.path.exists(path):
+        codes = builder.synth_reads(42 + rank, args.reads, args.rlen, args.genome, args.sub_rate, device=dev,
+                                    private_frac=0.05 if args.gpus > 1 else 0.0)
+        builder.build_from_codes(codes, path + ".tmp")
+        del codes
+        torch.cuda.empty_cache()
+        os.replace(path + ".tmp", path)
+    return path, time.time() - t0
+
+
+def host_cores():
+    """CPU share of this job: affinity mask, capped by the cgroup quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline(path, args, pmin):
+    """The oracle (our restatement of the reference client+server, same 3-array layout, one OpenMP thread per
+    prefix like metaenumerate.cpp:268, one in-process server per prefix) timed on a bounded sample of the same
+    workload: 6-mer prefixes of the same index, in random order, until the time budget is used."""
+    import random
+    import orc
+    ix = orc.Index(path)
+    threads = min(orc.lib().orc_max_threads(), host_cores())
+    allp = ["".join(p) for p in itertools.product("ACGT", repeat=6)]
+    random.Random(1).shuffle(allp)
+    done, nodes, t0 = 0, 0, time.time()
+    while done < len(allp) and time.time() - t0 < args.cpu_seconds:
+        batch = allp[done:done + threads]
+        _, st = orc.mine([ix], ["sample-0"], batch, fmin=args.fmin, pmin=pmin, emax=args.emax, threads=threads, discard=True)
+        nodes += st[0]
+        done += len(batch)
+    dt = time.time() - t0
+    ix.close()
+    return {"value": nodes / dt, "unit": "substrings/s", "cores": threads, "kind": "port",
+            "sample": "%d random 6-mer prefixes of 4096 of the same index (client enumeration + in-process merge/filter, "
+                      "one OpenMP thread per prefix), %d nodes in %.1f s" % (done, nodes, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import pydsm
+
+    path, build_s = build_index(args, rank, dev)
+    ix = pydsm.Index(path, device=local)
+    prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=args.prefix_len)] if args.prefix_len > 0 else [""]
+    pmin = 1 if world == 1 else 2
+
+    # exchange buffers owned by torch so that torch.distributed (RCCL) can all-gather them in place
+    allgather = None
+    exchange = None
+    if world > 1:
+        xbytes = 1 << 30
+        send = torch.empty(xbytes, dtype=torch.uint8, device=dev)
+        recv = torch.empty(2 * xbytes * world, dtype=torch.uint8, device=dev)
+
+        def allgather(sp, rp, nbytes, stream):  # one RCCL all-gather per frontier level
+            off = rp - recv.data_ptr()
+            assert sp == send.data_ptr() and off in (0, xbytes * world)
+            dist.all_gather_into_tensor(recv[off: off + nbytes * world], send[:nbytes])
+        exchange = (send.data_ptr(), recv.data_ptr(), xbytes)
+    stream = torch.cuda.current_stream().cuda_stream
+    miner = pydsm.Miner([ix], fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
+                        exchange=exchange, stream=stream)
+
+    tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
+           "device_ms": 0.0, "host_ms": 0.0, "cand": 0}
+
+    def step(record):
+        for st in (miner.mine_many(prefixes, text=False)[1],):
+            if record:
+                tot["reported"] += st.reported
+                tot["rank_ops"] += st.rank_ops
+                tot["lf_steps"] += st.lf_steps
+                tot["expand_ms"] += st.expand_ms
+                tot["launches"] += st.expand_launches
+                tot["tuples"] += st.tuples
+                tot["union"] += st.union_nodes
+                tot["device_ms"] += st.device_ms
+                tot["host_ms"] += st.host_ms
+                tot["cand"] += st.candidates
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(tot["reported"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        reported_all = float(tsum[1])
+    else:
+        reported_all = float(tot["reported"])
+    miner.close()
+
+    if rank == 0:
+        ach = tot["rank_ops"] * ALG_BYTES_PER_RANK / (tot["expand_ms"] * 1e-3) / 1e9 if tot["expand_ms"] > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 --pmc (see profiles/README)
+        if os.path.exists(tj):
+            try:
+                tinfo = json.load(open(tj))
+                if tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == args.prefix_len and tinfo.get("gpus") == args.gpus:
+                    traffic = tinfo.get("bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "enumerated substrings/sec (Emax=2.0)", "value": reported_all / dt, "unit": "substrings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if ix.n < 0xFFFFFFF0 else "u64",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic read set(s) of %d x %d bp (n=%d BWT symbols each), one FM-index per GPU, "
+                                   "fmin=%d Emax=%g pmin=%d, %d prefixes" % (world, args.reads, args.rlen, ix.n, args.fmin, args.emax, pmin, len(prefixes)),
+                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
+                         "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),
+                         "alg_bytes_per_launch": tot["rank_ops"] * ALG_BYTES_PER_RANK / max(1, tot["launches"])},
+            "detail": {"rank0_nodes_per_step": tot["reported"] / max(1, args.steps), "rank_ops_per_node": tot["rank_ops"] / max(1, tot["reported"]),
+                       "lf_per_node": tot["lf_steps"] / max(1, tot["reported"]), "tuples_per_step": tot["tuples"] / max(1, args.steps),
+                       "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
+                       "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
+                       "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,
+                       "index_hbm_bytes": ix.device_bytes()},
+        }
+        print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(path, args, pmin)
+        print(json.dumps(out), flush=True)
+    ix.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,9 +7,16 @@
 // left-extension intervals, fmin test and left-char code fused: "expand_kernel", the LF-step kernel),
 // samples exchange one [4F] frequency column per level (one all-gather), and the DFS order of the
 // reference's output is recovered at the end from subtree sizes (prefix sums over the levels).
+#include <sched.h>
+
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "scan.h"
@@ -51,6 +58,7 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 //   0 sp  1 ep  2..5 extmin[A,C,G,T]  6..9 extmax[A,C,G,T]     (EnumerateQuery.h:44-45, Query.h:110-111)
 // a node that is absent in this sample has sp > ep (sp = 1, ep = 0); an empty ext has min = 1, max = 0.
 constexpr int REC_FIELDS = 10;
+constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
 
 struct ExpandArgs {
     u32 F;            // frontier width
@@ -141,12 +149,16 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const P* __res
             }
         }
     }
+    // block-level reduction, then one add per counter into a shard picked by the block index: the four
+    // totals are summed over the shards at the end of the call (no hot word in L2)
+    __shared__ u64 red[4][4];
     u64 s0 = wave_sum_u64(n_rep), s1 = wave_sum_u64(n_lf), s2 = wave_sum_u64(n_rank), s3 = wave_sum_u64((u64)lines);
-    if ((threadIdx.x & 63) == 0) {
-        if (s0) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)s0);
-        if (s1) atomicAdd((unsigned long long*)&counters[1], (unsigned long long)s1);
-        if (s2) atomicAdd((unsigned long long*)&counters[2], (unsigned long long)s2);
-        if (s3) atomicAdd((unsigned long long*)&counters[3], (unsigned long long)s3);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
     }
 }
 
@@ -534,6 +546,212 @@ static inline dim3 grid_for(u64 n, int t = 256) { return dim3((unsigned)((n + t 
         if (!(var)) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes"); \
     } while (0)
 
+static unsigned host_threads() {
+    static unsigned n = 0;
+    if (!n) {
+        const char* e = getenv("DSM_HOST_THREADS");
+        long v = e ? atol(e) : 0;
+        if (v <= 0) {
+            cpu_set_t cs;
+            v = sched_getaffinity(0, sizeof cs, &cs) == 0 ? CPU_COUNT(&cs) : 1;
+            if (v > 16) v = 16;
+        }
+        n = (unsigned)(v < 1 ? 1 : v);
+    }
+    return n;
+}
+
+static const double LN2 = 0x1.62e42fefa39efp-1;  // the reference's log(2), folded by its compiler (metaserver.cpp:379,389)
+
+// One emit job: the candidates of one prefix, already in pinned host memory.  Exact entropy
+// (metaserver.cpp:366-389), the emin/emax test (:413), order-preserving compaction, delivery.
+struct RawBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* ensure(size_t n) {
+        if (n > cap) {
+            free(p);
+            cap = n + n / 4 + 4096;
+            p = malloc(cap);
+        }
+        return p;
+    }
+    ~RawBuf() { free(p); }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want);
+        if (e != hipSuccess) return fail(DSM_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+struct EmitSet {
+    PinBuf pin[5];   // path_off, pair_off, ids, freqs, paths (device order = post-order rank)
+    RawBuf out[6];   // o_path, o_pair, ent, paths, ids, freqs (kept tuples only)
+    RawBuf ent_all, keep;
+    u32 nt = 0;
+    bool busy = false;
+};
+
+static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const u32 nt = E.nt;
+    const u32* path_off = (const u32*)E.pin[0].p;
+    const u32* pair_off = (const u32*)E.pin[1].p;
+    const u32* ids = (const u32*)E.pin[2].p;
+    const u64* freqs = (const u64*)E.pin[3].p;
+    const char* paths = (const char*)E.pin[4].p;
+    double* ent = (double*)E.ent_all.ensure((size_t)nt * 8);
+    u8* keep = (u8*)E.keep.ensure(nt);
+    unsigned nth = host_threads();
+    if (nt < 65536) nth = 1;
+    const u32 per = (nt + nth - 1) / nth;
+    std::vector<u64> cnt_t(nth + 1, 0), cnt_p(nth + 1, 0), cnt_q(nth + 1, 0);
+    auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; };
+    auto pass1 = [&](unsigned t) {
+        u32 lo, hi;
+        range(t, lo, hi);
+        u64 kt = 0, kp = 0, kq = 0;
+        for (u32 r = lo; r < hi; ++r) {
+            u64 sumN = d;
+            double sumNlogN = 0;
+            for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
+                u64 f = freqs[q];
+                sumN += f;
+                sumNlogN += (double)(f + 1) * log((double)(f + 1)) / LN2;
+            }
+            double e = log((double)sumN) / LN2 - sumNlogN / (double)sumN;
+            ent[r] = e;
+            bool k = !(emax > 0 && (e < emin || e > emax));
+            keep[r] = k;
+            if (k) { ++kt; kp += path_off[r + 1] - path_off[r]; kq += pair_off[r + 1] - pair_off[r]; }
+        }
+        cnt_t[t + 1] = kt; cnt_p[t + 1] = kp; cnt_q[t + 1] = kq;
+    };
+    auto run_all = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; ++t) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto& x : th) x.join();
+    };
+    run_all(pass1);
+    for (unsigned t = 0; t < nth; ++t) { cnt_t[t + 1] += cnt_t[t]; cnt_p[t + 1] += cnt_p[t]; cnt_q[t + 1] += cnt_q[t]; }
+    const u64 W = cnt_t[nth], PW = cnt_p[nth], QW = cnt_q[nth];
+    u32* o_path = (u32*)E.out[0].ensure((W + 1) * 4);
+    u32* o_pair = (u32*)E.out[1].ensure((W + 1) * 4);
+    double* o_ent = (double*)E.out[2].ensure(W * 8 + 8);
+    char* o_paths = (char*)E.out[3].ensure(PW + 1);
+    u32* o_ids = (u32*)E.out[4].ensure(QW * 4 + 4);
+    u64* o_freqs = (u64*)E.out[5].ensure(QW * 8 + 8);
+    auto pass2 = [&](unsigned t) {
+        u32 lo, hi;
+        range(t, lo, hi);
+        u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
+        for (u32 r = lo; r < hi; ++r) {
+            if (!keep[r]) continue;
+            u32 pb = path_off[r], pl = path_off[r + 1] - pb, qb = pair_off[r], ql = pair_off[r + 1] - qb;
+            o_path[w] = (u32)pw; o_pair[w] = (u32)qw; o_ent[w] = ent[r];
+            memcpy(o_paths + pw, paths + pb, pl);
+            memcpy(o_ids + qw, ids + qb, (size_t)ql * 4);
+            memcpy(o_freqs + qw, freqs + qb, (size_t)ql * 8);
+            ++w; pw += pl; qw += ql;
+        }
+    };
+    run_all(pass2);
+    o_path[W] = (u32)PW;
+    o_pair[W] = (u32)QW;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    *n_tuples += W;
+    *n_pairs += QW;
+    if (W && sink) {
+        dsm_tuple_batch b;
+        b.ntuples = W;
+        b.path_off = o_path; b.path_bytes = o_paths; b.entropy = o_ent; b.pair_off = o_pair; b.ids = o_ids; b.freqs = o_freqs;
+        if (sink(ctx, &b)) return 1;
+    }
+    return 0;
+}
+
+// Host worker: emits prefix k while the GPU already expands prefix k+1 (two pinned sets).
+struct Emitter {
+    EmitSet set[2];
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> q;
+    bool stop = false, started = false;
+    int sink_err = 0;
+    u32 d = 1;
+    double emin = 0, emax = 0;
+    dsm_tuple_sink sink = nullptr;
+    void* ctx = nullptr;
+    u64 tuples = 0, pairs = 0;
+    double ms = 0;
+    int next = 0;
+
+    void loop() {
+        for (;;) {
+            int k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                k = q.front();
+                q.pop_front();
+            }
+            u64 t = 0, pq = 0;
+            double m = 0;
+            int rc = emit_job(set[k], d, emin, emax, sink, ctx, &t, &pq, &m);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                tuples += t; pairs += pq; ms += m;
+                if (rc) sink_err = 1;
+                set[k].busy = false;
+            }
+            cv.notify_all();
+        }
+    }
+    EmitSet& acquire() {  // a free set (blocks while both are being emitted)
+        std::unique_lock<std::mutex> lk(mu);
+        int k = next;
+        cv.wait(lk, [&] { return !set[k].busy; });
+        return set[k];
+    }
+    void submit() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!started) { started = true; th = std::thread([this] { loop(); }); }
+            set[next].busy = true;
+            q.push_back(next);
+            next ^= 1;
+        }
+        cv.notify_all();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return q.empty() && !set[0].busy && !set[1].busy; });
+    }
+    ~Emitter() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 template <typename P>
 class Engine {
   public:
@@ -637,13 +855,13 @@ class Engine {
         bpr_cap = (u64)nlocal * slots * (sizeof(P) + 1);
         if (p.exchange_send && p.exchange_recv && world > 1) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
-            // caller-owned buffers bound the frontier as well; recv is used as two halves
+            // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
             u64 cap_slots = p.exchange_bytes / ((u64)nlocal * (sizeof(P) + 1));
             if (cap_slots / 4 < Fcap) Fcap = (u32)(cap_slots / 4);
             bpr_cap = p.exchange_bytes;
             xsend = (u8*)p.exchange_send;
             xrecv[0] = (u8*)p.exchange_recv;
-            if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
+            xrecv[1] = (u8*)p.exchange_recv + (size_t)world * bpr_cap;  // second half: levels alternate
         } else {
             own_x = true;
             if (int rc = dalloc(xrecv[0], (size_t)world * bpr_cap)) return rc;
@@ -665,7 +883,7 @@ class Engine {
         if (int rc = dalloc(cand_idx, Fcap)) return rc;
         if (int rc = dalloc(cand_pairs, Fcap)) return rc;
         if (int rc = dalloc(cand_poff_node, Fcap)) return rc;
-        if (int rc = dalloc(d_counters, 8)) return rc;
+        if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 8 * sizeof(u32)));
         size_t used = 0;
@@ -711,7 +929,7 @@ class Engine {
         arena.off = 0;
         std::vector<LevelHost> L;
         L.reserve(512);
-        DSM_HIP(hipMemsetAsync(d_counters, 0, 8 * sizeof(u64), st));
+        DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
         DSM_HIP(hipEventRecord(ev0, st));
         float expand_ms = 0;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> evpairs;
@@ -883,8 +1101,13 @@ class Engine {
             (void)hipEventDestroy(pr.second);
         }
         stats.expand_ms += expand_ms;
-        u64 hc[4];
-        DSM_HIP(hipMemcpy(hc, d_counters, sizeof hc, hipMemcpyDeviceToHost));
+        u64 hc[4] = {0, 0, 0, 0};
+        {
+            std::vector<u64> sh((size_t)COUNTER_SHARDS * 8);
+            DSM_HIP(hipMemcpy(sh.data(), d_counters, sh.size() * sizeof(u64), hipMemcpyDeviceToHost));
+            for (int k = 0; k < COUNTER_SHARDS; ++k)
+                for (int c = 0; c < 4; ++c) hc[c] += sh[(size_t)k * 8 + c];
+        }
         stats.reported += hc[0];
         stats.lf_steps += hc[1];
         stats.rank_ops += hc[2];
@@ -956,22 +1179,36 @@ class Engine {
         ARENA_GET(d_freqs, u64, npairs);
         hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs);
         DSM_HIP(hipGetLastError());
-        // ---- to the host ------------------------------------------------------------------------
-        std::vector<u32> h_path_off((size_t)nt + 1), h_pair_off((size_t)nt + 1), h_ids(npairs);
-        std::vector<u64> h_freqs(npairs);
-        std::vector<char> h_paths(path_bytes);
-        DSM_HIP(hipMemcpyAsync(h_path_off.data(), path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(h_pair_off.data(), pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(h_ids.data(), d_ids, npairs * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(h_freqs.data(), d_freqs, npairs * 8, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(h_paths.data(), d_paths, path_bytes, hipMemcpyDeviceToHost, st));
+        // ---- to the host: pinned staging set, then the emitter thread takes over ------------------
+        EmitSet& E = emitter.acquire();
+        if (int rc = E.pin[0].ensure(((size_t)nt + 1) * 4)) return rc;
+        if (int rc = E.pin[1].ensure(((size_t)nt + 1) * 4)) return rc;
+        if (int rc = E.pin[2].ensure((size_t)npairs * 4)) return rc;
+        if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
+        if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
+        DSM_HIP(hipMemcpyAsync(E.pin[0].p, path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(E.pin[1].p, pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(E.pin[2].p, d_ids, npairs * 4, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(E.pin[3].p, d_freqs, npairs * 8, hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipMemcpyAsync(E.pin[4].p, d_paths, path_bytes, hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
-        return host_emit(nt, h_path_off, h_paths, h_pair_off, h_ids, h_freqs, sink, ctx);
+        E.nt = nt;
+        emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
+        emitter.submit();
+        return 0;
     }
+    Emitter emitter;
 
-    // exact entropy (metaserver.cpp:366-389,413) and delivery, in place
-    int host_emit(u32 nt, std::vector<u32>& path_off, std::vector<char>& paths, std::vector<u32>& pair_off, std::vector<u32>& ids,
-                  std::vector<u64>& freqs, dsm_tuple_sink sink, void* ctx);
+    // wait for the emitter and fold its counters into stats
+    int finish_emits() {
+        emitter.drain();
+        std::lock_guard<std::mutex> lk(emitter.mu);
+        stats.tuples += emitter.tuples; stats.pairs += emitter.pairs; stats.host_ms += emitter.ms;
+        emitter.tuples = emitter.pairs = 0;
+        emitter.ms = 0;
+        if (emitter.sink_err) { emitter.sink_err = 0; return fail(DSM_E_SINK, "tuple sink failed"); }
+        return 0;
+    }
 
     // ---- stream: byte offsets of every token from subtree sizes ------------------------------------
     int finish_stream(std::vector<LevelHost>& L, u32 nlev, dsm_byte_sink sink, void* ctx) {
@@ -1033,67 +1270,6 @@ class Engine {
     }
 };
 
-static const double LN2 = 0x1.62e42fefa39efp-1;  // the reference's log(2), folded by its compiler (metaserver.cpp:379,389)
-
-template <typename P>
-int Engine<P>::host_emit(u32 nt, std::vector<u32>& path_off, std::vector<char>& paths, std::vector<u32>& pair_off, std::vector<u32>& ids,
-                         std::vector<u64>& freqs, dsm_tuple_sink sink, void* ctx) {
-    hipEvent_t dummy = nullptr;
-    (void)dummy;
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    std::vector<double> ent(nt);
-    std::vector<u8> keep(nt);
-    const double emin = prm.emin, emax = prm.emax;
-    const u64 dd = d;
-    for (long r = 0; r < (long)nt; ++r) {
-        u64 sumN = dd;
-        double sumNlogN = 0;
-        for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
-            u64 f = freqs[q];
-            sumN += f;
-            sumNlogN += (double)(f + 1) * log((double)(f + 1)) / LN2;
-        }
-        double e = log((double)sumN) / LN2 - sumNlogN / (double)sumN;
-        ent[r] = e;
-        keep[r] = !(emax > 0 && (e < emin || e > emax));
-    }
-    // compact in place, order preserved
-    u32 w = 0, pw = 0, qw = 0;
-    std::vector<u32> o_path(1, 0), o_pair(1, 0);
-    o_path.reserve(nt + 1);
-    o_pair.reserve(nt + 1);
-    for (u32 r = 0; r < nt; ++r) {
-        if (!keep[r]) continue;
-        u32 pb = path_off[r], pe = path_off[r + 1], qb = pair_off[r], qe = pair_off[r + 1];
-        if (pw != pb) memmove(&paths[pw], &paths[pb], pe - pb);
-        if (qw != qb) {
-            memmove(&ids[qw], &ids[qb], (qe - qb) * 4);
-            memmove(&freqs[qw], &freqs[qb], (qe - qb) * 8);
-        }
-        pw += pe - pb;
-        qw += qe - qb;
-        ent[w++] = ent[r];
-        o_path.push_back(pw);
-        o_pair.push_back(qw);
-    }
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    stats.host_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-    stats.tuples += w;
-    stats.pairs += qw;
-    if (w && sink) {
-        dsm_tuple_batch b;
-        b.ntuples = w;
-        b.path_off = o_path.data();
-        b.path_bytes = paths.data();
-        b.entropy = ent.data();
-        b.pair_off = o_pair.data();
-        b.ids = ids.data();
-        b.freqs = freqs.data();
-        if (sink(ctx, &b)) return fail(DSM_E_SINK, "tuple sink failed");
-    }
-    return 0;
-}
 
 static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
     if (p && p->wide) return true;
@@ -1105,15 +1281,23 @@ static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
 struct MinerBase {
     virtual ~MinerBase() {}
     virtual int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
+    virtual int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
 };
 template <typename P>
 struct MinerT : MinerBase {
     Engine<P> e;
     int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
+        const char* one[1] = {prefix};
+        return run_many(one, 1, ts, bs, ctx, out);
+    }
+    // prefixes one after the other on the GPU; the host emits prefix k while prefix k+1 is being expanded
+    int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
         memset(&e.stats, 0, sizeof e.stats);
-        int rc = e.run(prefix, ts, bs, ctx);
+        int rc = 0;
+        for (int k = 0; k < n && !rc; ++k) rc = e.run(prefixes[k], ts, bs, ctx);
+        int rc2 = e.finish_emits();
         if (out) *out = e.stats;
-        return rc;
+        return rc ? rc : rc2;
     }
 };
 
@@ -1122,8 +1306,9 @@ static int mine_impl(dsm_index* const* idx, int n, const dsm_params* p, dsm_tupl
     std::unique_ptr<Engine<P>> e(new Engine<P>());
     int rc = e->init(idx, n, *p, false);
     if (!rc) rc = e->run(p->prefix, sink, nullptr, ctx);
+    int rc2 = e->finish_emits();
     if (stats) *stats = e->stats;
-    return rc;
+    return rc ? rc : rc2;
 }
 template <typename P>
 static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 maxdepth, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
@@ -1196,6 +1381,10 @@ int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* 
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
     if (!m) return fail(DSM_E_INVAL, "null miner");
     return reinterpret_cast<MinerBase*>(m)->run(prefix, nullptr, sink, ctx, stats);
+}
+int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    if (!m || !prefixes || nprefix < 0) return fail(DSM_E_INVAL, "dsm_miner_mine_many: bad arguments");
+    return reinterpret_cast<MinerBase*>(m)->run_many(prefixes, nprefix, sink, nullptr, ctx, stats);
 }
 void dsm_miner_destroy(dsm_miner* m) { delete reinterpret_cast<MinerBase*>(m); }
 

@@ -98,6 +98,7 @@ def lib():
         L.dsm_mine.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_miner_mine.argtypes = [C.c_void_p, C.c_char_p, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_miner_mine_many.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_enumerate.argtypes = [C.c_void_p, C.c_char_p, BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_destroy.argtypes = [C.c_void_p]
         L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -248,6 +249,15 @@ class Miner:
         cb = _tuple_sink(out, text, on_batch)
         st = Stats()
         _check(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)))
+        return (b"".join(out) if text else None), st
+
+    def mine_many(self, prefixes, text=True, on_batch=None):
+        """All prefixes in one call (host emission of prefix k overlaps GPU work on prefix k+1)."""
+        out = []
+        cb = _tuple_sink(out, text, on_batch)
+        st = Stats()
+        arr = (C.c_char_p * len(prefixes))(*[p.encode() for p in prefixes])
+        _check(lib().dsm_miner_mine_many(self.h, arr, len(prefixes), cb, None, C.byref(st)))
         return (b"".join(out) if text else None), st
 
     def enumerate(self, prefix, with_header=True, discard=False):

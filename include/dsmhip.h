@@ -154,7 +154,7 @@ typedef struct dsm_params {
     dsm_allgather_fn allgather;
     void* allgather_ctx;
     void* exchange_send;     /* optional caller-owned device buffers (e.g. torch tensors) of exchange_bytes */
-    void* exchange_recv;     /*   recv must hold world_size * exchange_bytes */
+    void* exchange_recv;     /*   recv must hold 2 * world_size * exchange_bytes (two halves, levels alternate) */
     uint64_t exchange_bytes;
     uint64_t arena_bytes;    /* device scratch budget; 0 = pick from free memory */
     uint32_t wide;           /* 1 = force 64-bit positions (all ranks must agree); 0 = from local index sizes */
@@ -173,6 +173,10 @@ int dsm_mine(dsm_index* const* idx, int nlocal, const dsm_params* p, dsm_tuple_s
 typedef struct dsm_miner dsm_miner;
 int dsm_miner_create(dsm_index* const* idx, int nlocal, const dsm_params* p, int stream_mode, dsm_miner** out);
 int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
+/* Several prefixes in one call: tuples arrive prefix by prefix in the given order (each prefix in the reference's
+ * post-order); the host-side exact-entropy pass of prefix k overlaps the GPU expansion of prefix k+1.  The sink is
+ * called from a library thread.  stats are summed over the prefixes. */
+int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats);
 void dsm_miner_destroy(dsm_miner* m);
 

@@ -573,7 +573,7 @@ char* orc_mine(int nidx, void** idx, const char** names, int nprefix, const char
 #pragma omp critical
 #endif
             { bad = true; errs[p] = g_err; }
-        } else { outs[p].assign(o, ol); free(o); }
+        } else { if (outlen) outs[p].assign(o, ol); free(o); }  // outlen == NULL: timing leg, text discarded
         loc[3] = st[0]; loc[4] = st[1]; loc[5] = st[2];
         for (int s = 0; s < nidx; ++s) free(bufs[s]);
 #ifdef _OPENMP

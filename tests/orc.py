@@ -117,12 +117,13 @@ def server(names, streams, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0):
     return data, tuple(st)
 
 
-def mine(indexes, names, prefixes, fmin=10, maxdepth=0xFFFFFFFF, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, threads=1):
+def mine(indexes, names, prefixes, fmin=10, maxdepth=0xFFFFFFFF, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, threads=1,
+         discard=False):
     n = C.c_size_t(0)
     st = (C.c_uint64 * 6)()
     hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
     p = lib().orc_mine(len(indexes), hs, _strs(names), len(prefixes), _strs(prefixes), fmin, maxdepth, pmin, pmax, mindepth,
-                       emin, emax, threads, C.byref(n), st)
+                       emin, emax, threads, None if discard else C.byref(n), st)
     if not p:
         raise RuntimeError(lib().orc_last_error().decode())
     data = C.string_at(p, n.value)

@@ -182,6 +182,10 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
         for p in ["T", "A", "GT", "A"]:
             got, st = m.mine(p)
             assert got == golden.server_out("toy3", "default", p)
+        ps = ["A", "C", "G", "T", "AC", "GT", "TTG"]
+        got, st = m.mine_many(ps)
+        assert got == b"".join(golden.server_out("toy3", "default", p) for p in ps)
+        assert st.tuples == got.count(b"\n")
     with pydsm_mod.Miner([idx[1]], fmin=2, stream_mode=True) as m:
         for p in ["C", "TTG", "C"]:
             got, st = m.enumerate(p)
