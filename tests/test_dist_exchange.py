@@ -1,0 +1,122 @@
+"""N>1 path, host side: the per-level all-gather plumbing with 2 gloo ranks on CPU (layout, halves, errors),
+and -- on the GPU box -- two ranks sharing the one GPU, each owning one sample, against the reference golden."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _cpu_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+    _init(rank, world, port)
+    from pydsm.dist import Exchange
+    ex = Exchange(1024, world, "cpu")
+    ok = True
+    for level, nbytes in enumerate([16, 1024, 40, 0, 8]):
+        ex.send[:nbytes] = torch.arange(nbytes, dtype=torch.uint8) + 17 * rank + level
+        half = (level & 1) * 1024 * world
+        ex.allgather(ex.send.data_ptr(), ex.recv.data_ptr() + half, nbytes)
+        for r in range(world):
+            want = (torch.arange(nbytes, dtype=torch.uint8) + 17 * r + level)
+            got = ex.recv[half + r * nbytes: half + (r + 1) * nbytes]
+            ok = ok and torch.equal(got, want)
+    # previous level's half is untouched by the next exchange
+    for bad in (lambda: ex.allgather(ex.send.data_ptr() + 1, ex.recv.data_ptr(), 8),
+                lambda: ex.allgather(ex.send.data_ptr(), ex.recv.data_ptr() + 8, 8),
+                lambda: ex.allgather(ex.send.data_ptr(), ex.recv.data_ptr(), 4096)):
+        try:
+            bad()
+            ok = False
+        except ValueError:
+            pass
+    q.put((rank, ok, ex.calls))
+    dist.destroy_process_group()
+
+
+def test_exchange_layout_two_gloo_ranks_cpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True, 5), (1, True, 5)]
+
+
+def _gpu_worker(rank, world, port, q, fmis, prefixes, kw):
+    sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+    _init(rank, world, port)
+    import pydsm
+    from pydsm.dist import Exchange
+    torch.cuda.set_device(0)
+    ex = Exchange(1 << 22, world, "cuda:0")
+    nloc = len(fmis) // world
+    idx = [pydsm.Index(f, device=0) for f in fmis[rank * nloc:(rank + 1) * nloc]]
+    out = []
+    with pydsm.Miner(idx, world_size=world, rank=rank, allgather=ex.allgather, exchange=ex.params(), **kw) as m:
+        for p in prefixes:
+            text, st = m.mine(p)
+            out.append((p, text, st.reported, st.union_nodes, st.pair_order_exact))
+    q.put((rank, out, ex.calls))
+    for ix in idx:
+        ix.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname,world,cfg", [("toy3", 3, "default"), ("five", 5, "default"), ("toy3", 3, "pmax2")])
+def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cfg):
+    import orc
+    from goldenlib import server_args_to_kw
+    m = golden.manifest["sets"][setname]
+    names = m["names"]
+    fmis = [golden.fmi(setname, n) for n in names]
+    kw = server_args_to_kw(m["server_cfgs"][cfg])
+    kw["fmin"] = m["fmin"]
+    prefixes = ["A", "GT"] if setname == "toy3" else ["C"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, fmis, prefixes, kw)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    # every rank computes the same union trie; tuples must equal the reference server's stdout
+    reported = {}
+    for rank, out, calls in res:
+        assert calls > 0
+        for p, text, rep, union, exact in out:
+            if p in ("A", "GT", "C") and (setname, p) != ("five", "GT"):
+                assert text == golden.server_out(setname, cfg, p), (rank, p)
+            assert exact == 1
+            reported.setdefault(p, []).append(rep)
+    # per-rank `reported` is that rank's own sample: the sum equals the oracle's client total
+    oidx = [orc.Index(f) for f in fmis]
+    for p in prefixes:
+        want = sum(ix.enumerate(n, p, fmin=m["fmin"])[1][0] for ix, n in zip(oidx, names))
+        assert sum(reported[p]) == want
