@@ -3,16 +3,24 @@
 // The reference walks each sample's suffix trie depth first, one LF call at a time
 // (EnumerateQuery::nextSymbol, EnumerateQuery.cpp:151-238) and merges the per-sample streams in a
 // single-threaded server (metaserver.cpp:269-486).  Here the trie of one prefix is expanded level by
-// level: every node of the current frontier is expanded by one GPU thread (all four children, all
-// left-extension intervals, fmin test and left-char code fused: "expand_kernel", the LF-step kernel),
-// samples exchange one [4F] frequency column per level (one all-gather), and the DFS order of the
-// reference's output is recovered at the end from subtree sizes (prefix sums over the levels).
+// level.  Per level:
+//   expand_kernel   one thread per frontier node: the four child intervals, the left-extension intervals
+//                   of every child, the fmin test and the left-char code, fused (the LF-step kernel).
+//                   Child records go to a compact buffer (block-wise allocation), the [4F] frequency
+//                   column and left-char codes go to the exchange buffer.
+//   (exchange)      one all-gather of the columns across ranks (RCCL through the host's callback).
+//   advance_*       union frontier of the next level: alive flags from the exchanged columns, one scan,
+//                   node links / reader counts / merged left chars / record handles in the down-sweep.
+//   order_kernel    iteration order of the reference's reader sets (only when d > 1).
+//   filter_kernel   metaserver's output predicates for the nodes whose children are now known.
+// The DFS order of the reference's output (post-order tuples, nested wire stream) is recovered at the end
+// of a prefix from subtree aggregates over the retained levels (prefix sums, no sorting).
 #include <sched.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <condition_variable>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -24,22 +32,24 @@
 namespace dsm {
 
 // ---------------------------------------------------------------------------------------------
-// small device helpers
+// rank on the bit-plane blocks
 // ---------------------------------------------------------------------------------------------
-template <typename P>
 struct RankCache {
-    u64 bi;
-    Blk16 r;
+    u64 bi;   // block currently held in r
+    u64 b1;   // block preloaded in r1 (the block of ep+1), ~0 when none
+    Blk16 r, r1;
 };
 
-// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x)
+// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
+// Positions are visited in ascending order, so the held block changes at most a few times; the block of
+// the interval's end was requested up front (its latency overlaps the first block's).
 template <typename P>
-__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache<P>& rc, u64 x, P out[4], u32& lines) {
+__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache& rc, u64 x, P out[4], u32& lines) {
     u64 bi = x >> BLK_SHIFT;
     if (bi != rc.bi) {
-        load_blk(ix.blk, bi, rc.r);
+        if (bi == rc.b1) rc.r = rc.r1;
+        else { load_blk(ix.blk, bi, rc.r); ++lines; }
         rc.bi = bi;
-        ++lines;
     }
     u32 c4[4];
     blk_counts(rc.r, (u32)(x & (BLK_SYMS - 1)), c4);
@@ -54,15 +64,17 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     return v;
 }
 
-// record layout (struct of arrays): field f of node i lives at rec[f * cap + i]
+// record layout (struct of arrays): field f of record r lives at rec[f * cap + r]
 //   0 sp  1 ep  2..5 extmin[A,C,G,T]  6..9 extmax[A,C,G,T]     (EnumerateQuery.h:44-45, Query.h:110-111)
-// a node that is absent in this sample has sp > ep (sp = 1, ep = 0); an empty ext has min = 1, max = 0.
+// an empty ext has min = 1, max = 0.  Records are addressed through a handle per frontier node (rp[v]);
+// DEAD = the node is absent from this sample.
 constexpr int REC_FIELDS = 10;
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
+constexpr u32 DEAD = 0xFFFFFFFFu;
 
 struct ExpandArgs {
     u32 F;            // frontier width
-    u32 cap;          // record capacity (stride)
+    u32 cap;          // record capacity (stride of both record buffers)
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
@@ -70,95 +82,129 @@ struct ExpandArgs {
     u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
 };
 
-// counters[0]=reported [1]=lf_steps [2]=rank_ops [3]=block lines fetched
+template <typename P> struct Vec4;
+template <> struct Vec4<u32> { typedef uint4 type; };
+template <> struct Vec4<u64> { typedef ulonglong4 type; };
+
+// counters (sharded): [0]=reported [1]=lf_steps [2]=rank_ops [3]=block lines fetched
 template <typename P>
-__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const P* __restrict__ rec, P* __restrict__ tmp,
-                                                     P* __restrict__ cfreq, u8* __restrict__ cleft, ExpandArgs a,
-                                                     u64* __restrict__ counters) {
+__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
+                                                     u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ cfreq,
+                                                     u8* __restrict__ cleft, ExpandArgs a, u64* __restrict__ counters) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    u64 n_rep = 0, n_lf = 0, n_rank = 0;
+    u64 n_lf = 0, n_rank = 0;
     u32 lines = 0;
-    if (i < a.F) {
-        const P sp = rec[0 * (size_t)a.cap + i], ep = rec[1 * (size_t)a.cap + i];
-        const size_t slot0 = (size_t)i * 4;
-        if (sp > ep) {
+    u32 r = DEAD;
+    if (i < a.F) r = rp[i];
+    const bool live = r != DEAD;
+    P sp = 1, ep = 0, emin[4], emax[4];
+    P Rsp[4], Rep[4], Rlo[4][4], Rhi[4][4];
+    P cf[4] = {0, 0, 0, 0};
+    u32 present = 0;  // bit c: child c is emitted
+    if (live) {
+        sp = rec[r];
+        ep = rec[(size_t)a.cap + r];
+        RankCache rc;
+        rc.bi = (u64)sp >> BLK_SHIFT;
+        rc.b1 = ((u64)ep + 1) >> BLK_SHIFT;
+        load_blk(ix.blk, rc.bi, rc.r);  // both ends of the interval are requested before anything waits
+        ++lines;
+        if (rc.b1 != rc.bi) { load_blk(ix.blk, rc.b1, rc.r1); ++lines; } else rc.b1 = ~0ull;
+        u32 ne = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cfreq[slot0 + c] = 0;
-        } else {
-            P emin[4], emax[4];
-            u32 ne = 0;
+        for (int k = 0; k < 4; ++k) {
+            emin[k] = rec[(size_t)(2 + k) * a.cap + r];
+            emax[k] = rec[(size_t)(6 + k) * a.cap + r];
+            ne += emin[k] <= emax[k];
+        }
+        rank4<P>(ix, rc, (u64)sp, Rsp, lines);  // LF(c, sp-1)
+        const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                emin[k] = rec[(size_t)(2 + k) * a.cap + i];
-                emax[k] = rec[(size_t)(6 + k) * a.cap + i];
-                ne += emin[k] <= emax[k];
+        for (int k = 0; k < 4; ++k) {
+            if (emin[k] <= emax[k]) {
+                rank4<P>(ix, rc, (u64)emin[k], Rlo[k], lines);
+                rank4<P>(ix, rc, (u64)emax[k] + 1, Rhi[k], lines);
             }
-            RankCache<P> rc;
-            rc.bi = ~0ull;
-            P Rsp[4], Rep[4], Rlo[4][4], Rhi[4][4];
-            rank4<P>(ix, rc, (u64)sp, Rsp, lines);  // LF(c, sp-1)
-            const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
+        }
+        rank4<P>(ix, rc, (u64)ep + 1, Rep, lines);  // LF(c, ep)
+        const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
+        if (single && a.allowed) n_rank += a.access_cost[lcode];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (emin[k] <= emax[k]) {
-                    rank4<P>(ix, rc, (u64)emin[k], Rlo[k], lines);
-                    rank4<P>(ix, rc, (u64)emax[k] + 1, Rhi[k], lines);
-                }
-            }
-            rank4<P>(ix, rc, (u64)ep + 1, Rep, lines);  // LF(c, ep)
-            const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
-            if (single && a.allowed) n_rank += a.access_cost[lcode];
-            const size_t tcap = (size_t)a.cap * 4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                P f = 0;
-                if ((a.allowed >> c) & 1u) {
-                    const P nsp = Rsp[c], nep = Rep[c] - 1;
-                    const bool nonempty = nsp <= nep;
-                    if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
-                    if (nonempty) {
-                        if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
-                        if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
-                            f = nep - nsp + 1;
-                            bool any = false, matches = false;
-                            u32 lc = 0;
-                            const size_t s = slot0 + c;
-                            tmp[0 * tcap + s] = nsp;
-                            tmp[1 * tcap + s] = nep;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                P cmin = 1, cmax = 0;
-                                if (emin[k] <= emax[k]) {  // EnumerateQuery.cpp:44-55
-                                    P lo = Rlo[k][c], hi = Rhi[k][c] - 1;
-                                    if (lo <= hi) {
-                                        cmin = lo; cmax = hi;
-                                        any = true; lc = k;
-                                        if (lo == nsp && hi == nep) matches = true;
-                                    }
-                                }
-                                tmp[(size_t)(2 + k) * tcap + s] = cmin;
-                                tmp[(size_t)(6 + k) * tcap + s] = cmax;
-                            }
-                            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
-                            cleft[s] = matches ? (u8)(1 + lc) : (any ? (u8)5 : (u8)0);
-                            ++n_rep;
-                        }
+        for (int c = 0; c < 4; ++c) {
+            if ((a.allowed >> c) & 1u) {
+                const P nsp = Rsp[c], nep = Rep[c] - 1;
+                const bool nonempty = nsp <= nep;
+                if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
+                if (nonempty) {
+                    if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
+                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
+                        cf[c] = nep - nsp + 1;
+                        present |= 1u << c;
                     }
                 }
-                cfreq[slot0 + c] = f;
             }
         }
     }
-    // block-level reduction, then one add per counter into a shard picked by the block index: the four
-    // totals are summed over the shards at the end of the call (no hot word in L2)
+    // ---- compact allocation of the child records: block scan + one atomic per block --------------
+    __shared__ u32 wtot[4];
+    __shared__ u32 sbase;
     __shared__ u64 red[4][4];
-    u64 s0 = wave_sum_u64(n_rep), s1 = wave_sum_u64(n_lf), s2 = wave_sum_u64(n_rank), s3 = wave_sum_u64((u64)lines);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
+    const u32 k = __popc(present);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 inc = k;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        u32 o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += o;
+    }
+    if (lane == 63) wtot[w] = inc;
+    u64 s0 = wave_sum_u64((u64)k), s1 = wave_sum_u64(n_lf), s2 = wave_sum_u64(n_rank), s3 = wave_sum_u64((u64)lines);
+    if (lane == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        sbase = tot ? atomicAdd(alloc, tot) : 0u;
+    }
     if (threadIdx.x < 4) {
         u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
+    }
+    __syncthreads();
+    u32 pos = sbase + (inc - k);
+    for (int q = 0; q < w; ++q) pos += wtot[q];
+    if (i < a.F) {
+        const size_t slot0 = (size_t)i * 4;
+        if (present) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!((present >> c) & 1u)) continue;
+                const P nsp = Rsp[c], nep = Rep[c] - 1;
+                bool any = false, matches = false;
+                u32 lc = 0;
+                const bool fits = pos < a.cap;  // overflow is detected by the host from *alloc
+                if (fits) { out[pos] = nsp; out[(size_t)a.cap + pos] = nep; }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    P cmin = 1, cmax = 0;
+                    if (emin[kk] <= emax[kk]) {  // EnumerateQuery.cpp:44-55
+                        P lo = Rlo[kk][c], hi = Rhi[kk][c] - 1;
+                        if (lo <= hi) {
+                            cmin = lo; cmax = hi;
+                            any = true; lc = kk;
+                            if (lo == nsp && hi == nep) matches = true;
+                        }
+                    }
+                    if (fits) { out[(size_t)(2 + kk) * a.cap + pos] = cmin; out[(size_t)(6 + kk) * a.cap + pos] = cmax; }
+                }
+                // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
+                cleft[slot0 + c] = matches ? (u8)(1 + lc) : (any ? (u8)5 : (u8)0);
+                tpos[slot0 + c] = pos;
+                ++pos;
+            }
+        }
+        typename Vec4<P>::type v;
+        v.x = cf[0]; v.y = cf[1]; v.z = cf[2]; v.w = cf[3];
+        *reinterpret_cast<typename Vec4<P>::type*>(cfreq + slot0) = v;
     }
 }
 
@@ -181,13 +227,17 @@ __device__ __forceinline__ u8 x_left(const Xchg& x, u32 g, u64 slot) {
     return rb[(u64)(g % x.nlocal) * x.slots + slot];
 }
 
-// per slot: alive in any sample?  number of samples, merged left char (metaserver.cpp:383-387)
+// ---------------------------------------------------------------------------------------------
+// advance: union frontier of the next level.  A thread owns 8 consecutive slots = 2 parents.
+// ---------------------------------------------------------------------------------------------
+constexpr int ADV_SLOTS = 8;
+constexpr int ADV_TILE = 256 * ADV_SLOTS;
+
+// alive in any sample?  number of samples, merged left char (metaserver.cpp:383-387)
 template <typename P>
-__global__ void flags_kernel(Xchg x, u32* __restrict__ flag, u16* __restrict__ nTslot, u8* __restrict__ mleft_slot) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= x.slots) return;
+__device__ __forceinline__ u32 slot_eval(const Xchg& x, u64 j, u8& ml) {
     u32 nT = 0;
-    u8 ml = 0xFF;
+    ml = 0xFF;
     for (u32 g = 0; g < x.d; ++g) {
         if (x_freq<P>(x, g, j) != 0) {
             ++nT;
@@ -195,65 +245,96 @@ __global__ void flags_kernel(Xchg x, u32* __restrict__ flag, u16* __restrict__ n
             ml = ml == 0xFF ? l : (ml == l ? ml : (u8)5);
         }
     }
-    flag[j] = nT ? 1u : 0u;
-    nTslot[j] = (u16)nT;
-    mleft_slot[j] = ml;
+    return nT;
 }
 
-// new union nodes: parent link, symbol, #samples, merged left char, slot in the exchange buffer
-__global__ void node_kernel(u64 slots, const u32* __restrict__ flag, const u32* __restrict__ newidx, const u16* __restrict__ nTslot,
-                            const u8* __restrict__ mleft_slot, u32* __restrict__ parent, u8* __restrict__ sym, u16* __restrict__ nT,
-                            u8* __restrict__ mleft, u32* __restrict__ slot_of) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= slots || !flag[j]) return;
-    u32 v = newidx[j];
-    parent[v] = (u32)(j >> 2);
-    sym[v] = (u8)(j & 3);
-    nT[v] = nTslot[j];
-    mleft[v] = mleft_slot[j];
-    slot_of[v] = (u32)j;
-}
-
-// per parent: first child index, number of children, "single child carrying every reader" (metaserver.cpp:416-417)
-__global__ void parent_kernel(u32 F, const u32* __restrict__ flag, const u32* __restrict__ newidx, const u16* __restrict__ nTslot,
-                              const u16* __restrict__ nT, u32* __restrict__ firstchild, u8* __restrict__ nchild, u8* __restrict__ samechild) {
-    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= F) return;
-    u32 nc = 0, last = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (flag[(u64)u * 4 + c]) { ++nc; last = c; }
-    firstchild[u] = newidx[(u64)u * 4];
-    nchild[u] = (u8)nc;
-    samechild[u] = (nc == 1 && nTslot[(u64)u * 4 + last] == nT[u]) ? 1 : 0;
-}
-
-// move the surviving children of one local sample from the temp slots to the next frontier
 template <typename P>
-__global__ void copy_kernel(u64 slots, u32 cap, const u32* __restrict__ flag, const u32* __restrict__ newidx,
-                            const P* __restrict__ cfreq, const P* __restrict__ tmp, P* __restrict__ next) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= slots || !flag[j]) return;
-    u32 v = newidx[j];
-    if (cfreq[j] != 0) {
-        const size_t tcap = (size_t)cap * 4;
+__global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __restrict__ sums) {
+    const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
+    u32 s = 0;
+    if (x.d == 1) {
+        const P* f = reinterpret_cast<const P*>(x.base);
 #pragma unroll
-        for (int f = 0; f < REC_FIELDS; ++f) next[(size_t)f * cap + v] = tmp[(size_t)f * tcap + j];
+        for (int k = 0; k < ADV_SLOTS; ++k)
+            if (base + k < x.slots) s += f[base + k] != 0;
     } else {
-        next[v] = 1;
-        next[(size_t)cap + v] = 0;
+        for (int k = 0; k < ADV_SLOTS; ++k)
+            if (base + k < x.slots) { u8 ml; s += slot_eval<P>(x, base + k, ml) != 0; }
     }
+    u32 tot;
+    block_exclusive_scan<u32>(s, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-// stream mode keeps freq and left char of every node
+struct AdvanceOut {
+    u32* slot;        // retained: 4*parent + sym of every new node
+    u32* firstchild;  // retained, per parent (+ sentinel written by the host)
+    u16* nT;          // per new node
+    u8* mleft;        // per new node
+    u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
+    const u16* parent_nT;
+    // per local sample record handles
+    u32* rp[8];
+    const u32* tpos[8];
+    u32 nlocal, rank;
+    // stream mode (d == 1)
+    void* keep_freq;
+    u8* keep_left;
+};
+
 template <typename P>
-__global__ void keep_kernel(u64 slots, const u32* __restrict__ flag, const u32* __restrict__ newidx, const P* __restrict__ cfreq,
-                            const u8* __restrict__ cleft, P* __restrict__ freq, u8* __restrict__ left) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= slots || !flag[j]) return;
-    u32 v = newidx[j];
-    freq[v] = cfreq[j];
-    left[v] = cleft[j];
+__global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __restrict__ offsets, AdvanceOut o, u32* __restrict__ total) {
+    const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
+    u32 nTs[ADV_SLOTS];
+    u8 mls[ADV_SLOTS];
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < ADV_SLOTS; ++k) {
+        nTs[k] = 0; mls[k] = 0xFF;
+        if (base + k < x.slots) {
+            if (x.d == 1) {
+                nTs[k] = reinterpret_cast<const P*>(x.base)[base + k] != 0;
+                if (nTs[k]) mls[k] = x.base[x.slots * sizeof(P) + base + k];
+            } else {
+                nTs[k] = slot_eval<P>(x, base + k, mls[k]);
+            }
+        }
+        s += nTs[k] != 0;
+    }
+    u32 tot;
+    u32 ex = block_exclusive_scan<u32>(s, &tot);
+    const u32 off = offsets ? offsets[blockIdx.x] : 0u;
+    ex += off;
+    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + tot;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const u64 j0 = base + 4 * half;
+        if (j0 >= x.slots) break;
+        const u32 u = (u32)(j0 >> 2);
+        o.firstchild[u] = ex;
+        u32 nc = 0, lastT = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * half + c;
+            if (!nTs[k]) continue;
+            const u64 j = j0 + c;
+            const u32 v = ex++;
+            ++nc;
+            lastT = nTs[k];
+            o.slot[v] = (u32)j;
+            o.nT[v] = (u16)nTs[k];
+            o.mleft[v] = mls[k];
+            for (u32 sl = 0; sl < o.nlocal; ++sl) {
+                const u32 g = o.rank * o.nlocal + sl;
+                o.rp[sl][v] = x_freq<P>(x, g, j) != 0 ? o.tpos[sl][j] : DEAD;
+            }
+            if (o.keep_left) {
+                reinterpret_cast<P*>(o.keep_freq)[v] = reinterpret_cast<const P*>(x.base)[j];
+                o.keep_left[v] = mls[k];
+            }
+        }
+        o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,19 +344,21 @@ __global__ void keep_kernel(u64 slots, const u32* __restrict__ flag, const u32* 
 // round (metaserver.cpp:159-189, 322-339).  Orders are nibble-packed, first iterated id in bits 0-3.
 // ---------------------------------------------------------------------------------------------
 template <typename P>
-__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, const u32* __restrict__ flag,
-                             const u32* __restrict__ newidx, u64* __restrict__ order_next) {
+__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, const u32* __restrict__ firstchild,
+                             u64* __restrict__ order_next) {
     u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= F) return;
     const u32 cnt = nT[u];
     const u64 ord = order[u];
     u32 mask[16];
+    u32 alive = 0;
     for (u32 k = 0; k < cnt; ++k) {
         u32 r = (u32)((ord >> (4 * k)) & 15);
         u32 m = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) m |= (x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
         mask[k] = m;  // indexed by position in the parent's order
+        alive |= m;
     }
     u64 ins[4] = {0, 0, 0, 0};
     u32 icnt[4] = {0, 0, 0, 0};
@@ -288,16 +371,16 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
             ++icnt[f];
         }
     }
+    u32 v = firstchild[u];
     for (int i = 0; i < 4; ++i) {
         if (!icnt[i]) continue;
         // iteration order of children[i] = reverse insertion order
         u64 rev = 0;
         for (u32 k = 0; k < icnt[i]; ++k) rev |= ((ins[i] >> (4 * k)) & 15) << (4 * (icnt[i] - 1 - k));
-        order_next[newidx[(u64)u * 4 + i]] = rev;
+        order_next[v++] = rev;
         // next round: the readers of this child (in its iteration order) read their next child
         for (u32 k = 0; k < icnt[i]; ++k) {
             u32 r = (u32)((rev >> (4 * k)) & 15);
-            // find r's mask: position of r in the parent's order
             u32 m = 0;
             for (u32 q = 0; q < cnt; ++q)
                 if (((ord >> (4 * q)) & 15) == r) m = mask[q];
@@ -322,9 +405,10 @@ struct FilterArgs {
 
 // output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
 // within 1e-9 of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
+// key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
 template <typename P>
 __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u8* __restrict__ mleft,
-                              const u8* __restrict__ nchild, const u8* __restrict__ samechild, u32* __restrict__ cand, u32* __restrict__ cand_pairs) {
+                              const u32* __restrict__ firstchild, const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= a.F) return;
     bool out = true;
@@ -332,7 +416,7 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
     if (a.depth < a.mindepth) out = false;
     if (a.pmax != 0 && t > a.pmax) out = false;
     if (t < a.pmin) out = false;
-    if (nchild[v] == 1 && samechild[v]) out = false;
+    if (firstchild[v + 1] - firstchild[v] == 1 && samechild[v]) out = false;
     const u8 l = mleft[v];
     if (l >= 1 && l <= 4) out = false;
     if (out && a.emax > 0) {
@@ -349,19 +433,19 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
         double e = log2((double)sumN) - s / (double)sumN;
         if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
     }
-    cand[v] = out ? 1u : 0u;
-    cand_pairs[v] = out ? t : 0u;
+    cand[v] = out ? 1 : 0;
+    key[v] = out ? (1ull | ((u64)t << 32)) : 0ull;
 }
 
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
 template <typename P>
 __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u64* __restrict__ order,
-                                  const u32* __restrict__ cand, const u32* __restrict__ cidx, const u32* __restrict__ poff,
+                                  const u8* __restrict__ cand, const u64* __restrict__ keyscan,
                                   u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= a.F || !cand[v]) return;
-    const u32 k = cidx[v];
-    u32 o = poff[v];
+    const u32 k = (u32)(keyscan[v] & 0xFFFFFFFFu);
+    u32 o = (u32)(keyscan[v] >> 32);
     cand_node[k] = v;
     cand_poff[k] = o;
     const u64 j = slot_of[v];
@@ -381,25 +465,24 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ 
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
-// bottom-up: agg[v] = own[v] + sum over children agg_child
+// bottom-up: agg[v] = own[v] + sum over children agg_child          (children of v: [fc[v], fc[v+1]) )
 template <typename T, typename OwnT>
-__global__ void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const u8* __restrict__ nchild,
-                          const T* __restrict__ child_agg, T* __restrict__ agg) {
+__global__ void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const T* __restrict__ child_agg, T* __restrict__ agg) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
     T s = own ? (T)own[v] : (T)1;
-    u32 fc = firstchild[v], nc = nchild[v];
+    u32 fc = firstchild[v], nc = firstchild[v + 1] - fc;
     for (u32 k = 0; k < nc; ++k) s += child_agg[fc + k];
     agg[v] = s;
 }
 // top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]
 template <typename T>
-__global__ void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild, const u8* __restrict__ nchild,
-                            const T* __restrict__ child_agg, T* __restrict__ child_start) {
+__global__ void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild, const T* __restrict__ child_agg,
+                            T* __restrict__ child_start) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
     T s = start[v] + lead;
-    u32 fc = firstchild[v], nc = nchild[v];
+    u32 fc = firstchild[v], nc = firstchild[v + 1] - fc;
     for (u32 k = 0; k < nc; ++k) {
         child_start[fc + k] = s;
         s += child_agg[fc + k];
@@ -418,8 +501,7 @@ __global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, c
 }
 
 struct LevelDev {
-    const u32* parent;
-    const u8* sym;
+    const u32* slot;
     const u32* cand_node;
     const u32* cand_poff;
     const u32* ids;
@@ -454,8 +536,9 @@ __global__ void tuple_fill_kernel(u32 nt, const LevelDev* __restrict__ lv, const
     u32 v = L.cand_node[k];
     u32 po = path_off[r];
     for (u32 l = lvl; l >= 1; --l) {
-        paths[po + l - 1] = "ACGT"[lv[l].sym[v]];
-        v = lv[l].parent[v];
+        u32 s = lv[l].slot[v];
+        paths[po + l - 1] = "ACGT"[s & 3];
+        v = s >> 2;
     }
 }
 
@@ -484,14 +567,14 @@ __global__ void stream_own_kernel(u32 F, u32 depth, u64 rbase, const P* __restri
 }
 
 template <typename P>
-__global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u8* __restrict__ sym, const P* __restrict__ freq, const u8* __restrict__ left,
+__global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u32* __restrict__ slot, const P* __restrict__ freq, const u8* __restrict__ left,
                                     const u64* __restrict__ pre, const u64* __restrict__ sz, const u64* __restrict__ off, const u64* __restrict__ bytes,
                                     const u64* __restrict__ own, u8* __restrict__ out) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
     u8* p = out + off[v];
     p[0] = '(';
-    p[1] = (u8)"ACGT"[sym[v]];
+    p[1] = (u8)"ACGT"[slot[v] & 3];
     u8* q = out + off[v] + bytes[v] - (own[v] - 2);
     q += put_varint(q, (u64)freq[v]);
     if (depth <= 6) { *q++ = 'R'; q += put_varint(q, rbase + pre[v] + sz[v]); }
@@ -516,12 +599,10 @@ struct Arena {
 
 struct LevelHost {
     u32 n = 0;
-    u32* parent = nullptr;
-    u8* sym = nullptr;
-    u32* firstchild = nullptr;
-    u8* nchild = nullptr;
+    u32* slot = nullptr;        // 4 * parent + sym
+    u32* firstchild = nullptr;  // n + 1 entries
     // mine
-    u32* cand_flag = nullptr;  // per node
+    u8* cand_flag = nullptr;
     u32 ncand = 0, npairs = 0;
     u32* cand_node = nullptr;
     u32* cand_poff = nullptr;
@@ -765,33 +846,38 @@ class Engine {
 
     // frontier buffers
     u32 Fcap = 0;
-    std::vector<P*> rec[2];
-    std::vector<P*> tmp;
+    std::vector<P*> rec[2];     // compact child records, ping-pong by level
+    std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
+    std::vector<u32*> tpos;     // record handle per child slot of the level being expanded
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
-    bool own_x = false;
     u64 bpr_cap = 0;
-    u32 *flag = nullptr, *newidx = nullptr, *scan_tmp = nullptr;
-    u16 *nTslot = nullptr, *nT[2] = {nullptr, nullptr};
-    u8 *mleft_slot = nullptr, *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
-    u32* slot_of[2] = {nullptr, nullptr};
+    u32 *adv_sums = nullptr, *scan_tmp = nullptr;
+    u16* nT[2] = {nullptr, nullptr};
+    u8 *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
     u64* order[2] = {nullptr, nullptr};
-    u32 *cand_idx = nullptr, *cand_pairs = nullptr, *cand_poff_node = nullptr;
+    u64 *cand_key = nullptr, *cand_keyscan = nullptr, *scan_tmp64 = nullptr;
     u64* d_counters = nullptr;
+    u32* d_alloc = nullptr;   // [nlocal] compact-record allocation counters
+    P* stage_freq = nullptr;  // stream mode: freq / left char of the new level before they move to the arena
+    u8* stage_left = nullptr;
     u32* d_totals = nullptr;
-    u32* h_totals = nullptr;  // pinned
+    u64* d_totals64 = nullptr;
+    u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, then u64 totals
     std::vector<void*> owned;
     Arena arena;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evpool;
     dsm_stats stats;
+    u64 lines_fetched = 0;
+    Emitter emitter;
 
     ~Engine() {
         for (void* p : owned) (void)hipFree(p);
         if (h_totals) (void)hipHostFree(h_totals);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (evA) (void)hipEventDestroy(evA);
-        if (evB) (void)hipEventDestroy(evB);
+        for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
     }
 
     template <class T> int dalloc(T*& p, size_t n) {
@@ -812,6 +898,7 @@ class Engine {
         rank = world > 1 ? (int)p.rank : 0;
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
+        if (n > 8) return fail(DSM_E_INVAL, "at most 8 local indexes per process");
         d = (u32)(world * nlocal);
         if (d > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
         st = (hipStream_t)p.stream;
@@ -835,24 +922,16 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * REC_FIELDS + 4 * REC_FIELDS) * sizeof(P)  // rec x2 + tmp
-                   + (u64)nlocal * 4 * (sizeof(P) + 1)                           // send
-                   + 2ull * d * 4 * (sizeof(P) + 1)                              // recv x2
-                   + 4 * (4 + 4 + 2 + 1) + 2 * (2 + 1 + 4 + 8) + 1 + 12 + 64;
+        u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4 * 4)   // rec x2, rp x2, tpos
+                   + (u64)nlocal * 4 * (sizeof(P) + 1)                         // send
+                   + 2ull * d * 4 * (sizeof(P) + 1)                            // recv x2
+                   + 2 * (2 + 1 + 8) + 1 + 16 + 64;
         u64 fc = budget / 3 / perF;
-        if (fc > (1u << 27)) fc = 1u << 27;
+        if (fc > (1u << 28)) fc = 1u << 28;
         if (fc > fbound) fc = fbound;
         if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         Fcap = (u32)fc;
-        const u64 slots = (u64)Fcap * 4;
-        for (int s = 0; s < nlocal; ++s) {
-            P *a, *b, *t;
-            if (int rc = dalloc(a, (size_t)REC_FIELDS * Fcap)) return rc;
-            if (int rc = dalloc(b, (size_t)REC_FIELDS * Fcap)) return rc;
-            if (int rc = dalloc(t, (size_t)REC_FIELDS * slots)) return rc;
-            rec[0].push_back(a); rec[1].push_back(b); tmp.push_back(t);
-        }
-        bpr_cap = (u64)nlocal * slots * (sizeof(P) + 1);
+        bpr_cap = (u64)nlocal * 4 * Fcap * (sizeof(P) + 1);
         if (p.exchange_send && p.exchange_recv && world > 1) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
             // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
@@ -863,29 +942,42 @@ class Engine {
             xrecv[0] = (u8*)p.exchange_recv;
             xrecv[1] = (u8*)p.exchange_recv + (size_t)world * bpr_cap;  // second half: levels alternate
         } else {
-            own_x = true;
             if (int rc = dalloc(xrecv[0], (size_t)world * bpr_cap)) return rc;
             if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
             if (world > 1) { if (int rc = dalloc(xsend, (size_t)bpr_cap)) return rc; }
         }
-        if (int rc = dalloc(flag, slots)) return rc;
-        if (int rc = dalloc(newidx, slots)) return rc;
-        if (int rc = dalloc(scan_tmp, scan_tmp_elems(slots) + 8)) return rc;
-        if (int rc = dalloc(nTslot, slots)) return rc;
-        if (int rc = dalloc(mleft_slot, slots)) return rc;
+        const u64 slots = (u64)Fcap * 4;
+        for (int s = 0; s < nlocal; ++s) {
+            P *a, *b;
+            u32 *r0, *r1, *tp;
+            if (int rc = dalloc(a, (size_t)REC_FIELDS * Fcap)) return rc;
+            if (int rc = dalloc(b, (size_t)REC_FIELDS * Fcap)) return rc;
+            if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
+            if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
+            if (int rc = dalloc(tp, (size_t)slots)) return rc;
+            rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp);
+        }
+        const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
+        if (int rc = dalloc(adv_sums, nadv)) return rc;
+        if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
             if (int rc = dalloc(mleft[k], Fcap)) return rc;
-            if (int rc = dalloc(slot_of[k], Fcap)) return rc;
             if (int rc = dalloc(order[k], Fcap)) return rc;
         }
         if (int rc = dalloc(samechild, Fcap)) return rc;
-        if (int rc = dalloc(cand_idx, Fcap)) return rc;
-        if (int rc = dalloc(cand_pairs, Fcap)) return rc;
-        if (int rc = dalloc(cand_poff_node, Fcap)) return rc;
+        if (stream_mode) {
+            if (int rc = dalloc(stage_freq, Fcap)) return rc;
+            if (int rc = dalloc(stage_left, Fcap)) return rc;
+        }
+        if (int rc = dalloc(cand_key, Fcap)) return rc;
+        if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
+        if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
+        if (int rc = dalloc(d_alloc, 8)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
-        DSM_HIP(hipHostMalloc((void**)&h_totals, 8 * sizeof(u32)));
+        if (int rc = dalloc(d_totals64, 4)) return rc;
+        DSM_HIP(hipHostMalloc((void**)&h_totals, 64 * sizeof(u32)));
         size_t used = 0;
         {
             size_t f2 = 0, t2 = 0;
@@ -898,8 +990,6 @@ class Engine {
         arena.cap = arena_b;
         DSM_HIP(hipEventCreate(&ev0));
         DSM_HIP(hipEventCreate(&ev1));
-        DSM_HIP(hipEventCreate(&evA));
-        DSM_HIP(hipEventCreate(&evB));
         return 0;
     }
 
@@ -913,13 +1003,16 @@ class Engine {
         return x;
     }
 
-    int read_totals(int n) {
-        DSM_HIP(hipMemcpyAsync(h_totals, d_totals, n * sizeof(u32), hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipStreamSynchronize(st));
-        return 0;
+    hipEvent_t pool_event(size_t k) {
+        while (evpool.size() <= k) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            evpool.push_back(e);
+        }
+        return evpool[k];
     }
 
-    // Runs one prefix.  mine: tuples to `tsink`; stream: wire bytes to `bsink`.
+    // Runs one prefix.  mine: tuples to `tsink` (through the emitter thread); stream: wire bytes to `bsink`.
     int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx) {
         const std::string prefix = prefix_c ? prefix_c : "";
         for (char ch : prefix)
@@ -931,8 +1024,7 @@ class Engine {
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
         DSM_HIP(hipEventRecord(ev0, st));
-        float expand_ms = 0;
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> evpairs;
+        size_t nev = 0;
 
         // ---- level 0: the root (EnumerateQuery::enumerate, EnumerateQuery.cpp:9-37) --------------
         const char* bases = "ACGT";
@@ -942,22 +1034,22 @@ class Engine {
             h[0] = 0;
             h[1] = (P)(m.n - 1);
             for (int a = 0; a < 4; ++a) {
-                u64 lo = m.C[(int)bases[a]], hi = m.C[(int)bases[a]] + m.codes[(int)bases[a]].count;  // LF(a,-1), LF(a,n-1)
-                if (lo <= hi - 1 && m.codes[(int)bases[a]].count) { h[2 + a] = (P)lo; h[6 + a] = (P)(hi - 1); }
+                u64 lo = m.C[(int)bases[a]], cnt = m.codes[(int)bases[a]].count;  // LF(a,-1), LF(a,n-1)
+                if (cnt) { h[2 + a] = (P)lo; h[6 + a] = (P)(lo + cnt - 1); }
                 else { h[2 + a] = 1; h[6 + a] = 0; }
             }
             for (int f = 0; f < REC_FIELDS; ++f)
                 DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Fcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
+            const u32 zero = 0;
+            DSM_HIP(hipMemcpyAsync(rp[0][s], &zero, sizeof(u32), hipMemcpyHostToDevice, st));
             stats.lf_steps += 8;
             for (int a = 0; a < 4; ++a) stats.rank_ops += 2 * m.lfcost[a];
         }
         {
             LevelHost root;
             root.n = 1;
-            ARENA_GET(root.parent, u32, 1);
-            ARENA_GET(root.sym, u8, 1);
-            ARENA_GET(root.firstchild, u32, 1);
-            ARENA_GET(root.nchild, u8, 1);
+            ARENA_GET(root.slot, u32, 1);
+            ARENA_GET(root.firstchild, u32, 2);
             L.push_back(root);
             u16 rootT = (u16)d;
             DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
@@ -969,7 +1061,7 @@ class Engine {
         const bool exact_order = d >= 2 && d <= 13;
         stats.pair_order_exact = (d <= 13) ? 1 : 0;
 
-        int cur = 0;      // rec / nT / order ping-pong index of the current level
+        int cur = 0;      // ping-pong index of the current level (rec, rp, nT, mleft, order)
         int xcur = 0;     // exchange buffer that will receive the current level's children
         u32 F = 1;
         u32 depth = 0;
@@ -978,6 +1070,7 @@ class Engine {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
             const u64 bpr = (u64)nlocal * slots * (sizeof(P) + 1);
+            const int nxt = cur ^ 1;
             u8* send = world > 1 ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
@@ -990,10 +1083,9 @@ class Engine {
                 ea.allowed = depth >= prm.maxdepth ? 0u : 15u;  // EnumerateQuery.cpp:153
                 ea.symbol_phase = 1;
             }
-            hipEvent_t ea0, ea1;
-            DSM_HIP(hipEventCreate(&ea0));
-            DSM_HIP(hipEventCreate(&ea1));
-            evpairs.push_back({ea0, ea1});
+            DSM_HIP(hipMemsetAsync(d_alloc, 0, 8 * sizeof(u32), st));
+            hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
+            if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             DSM_HIP(hipEventRecord(ea0, st));
             for (int s = 0; s < nlocal; ++s) {
                 const IndexMeta& m = idx[s]->meta;
@@ -1001,7 +1093,8 @@ class Engine {
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
                 P* cf = reinterpret_cast<P*>(send) + (size_t)s * slots;
                 u8* cl = send + (size_t)nlocal * slots * sizeof(P) + (size_t)s * slots;
-                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rec[cur][s], tmp[s], cf, cl, ea, d_counters);
+                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
+                                   tpos[s], cf, cl, ea, d_counters);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
@@ -1013,38 +1106,54 @@ class Engine {
             }
             Xchg x = xview(xcur, slots, bpr);
             // ---- union frontier of the next level -------------------------------------------------
-            hipLaunchKernelGGL((flags_kernel<P>), grid_for(slots), dim3(256), 0, st, x, flag, nTslot, mleft_slot);
-            exclusive_scan<u32, u32>(flag, newidx, slots, scan_tmp, d_totals, st);
-            if (int rc = read_totals(1)) return rc;
-            const u32 Fn = h_totals[0];
-            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
-            const int nxt = cur ^ 1;
             LevelHost& me = L[depth];
             LevelHost child;
+            // the arena hands out memory past `off`; the new level's arrays are claimed after Fn is known, so
+            // the down-sweep writes into a provisional window that is then committed
+            const size_t mark = arena.off;
+            u32* new_slot = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
+            if (!new_slot) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
+            void* keep_freq = stream_mode ? (void*)stage_freq : nullptr;
+            u8* keep_left = stream_mode ? stage_left : nullptr;
+            const u32 nb = (u32)((slots + ADV_TILE - 1) / ADV_TILE);
+            AdvanceOut ao;
+            memset(&ao, 0, sizeof ao);
+            ao.slot = new_slot; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.mleft = mleft[nxt]; ao.samechild = samechild;
+            ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank; ao.keep_freq = keep_freq; ao.keep_left = keep_left;
+            for (int s = 0; s < nlocal; ++s) { ao.rp[s] = rp[nxt][s]; ao.tpos[s] = tpos[s]; }
+            if (nb == 1) {
+                hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
+            } else {
+                hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums);
+                exclusive_scan<u32, u32>(adv_sums, adv_sums, nb, scan_tmp, d_totals, st);
+                hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
+            }
+            DSM_HIP(hipMemcpyAsync(h_totals, d_totals, sizeof(u32), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, 8 * sizeof(u32), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipStreamSynchronize(st));
+            const u32 Fn = h_totals[0];
+            for (int s = 0; s < nlocal; ++s)
+                if (h_totals[8 + s] > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+            DSM_HIP(hipMemcpyAsync(me.firstchild + F, &h_totals[0], sizeof(u32), hipMemcpyHostToDevice, st));  // sentinel
+            // commit the provisional window at its real size
+            arena.off = mark;
             child.n = Fn;
-            hipLaunchKernelGGL(parent_kernel, grid_for(F), dim3(256), 0, st, F, flag, newidx, nTslot, nT[cur], me.firstchild, me.nchild, samechild);
             if (Fn) {
-                ARENA_GET(child.parent, u32, Fn);
-                ARENA_GET(child.sym, u8, Fn);
-                ARENA_GET(child.firstchild, u32, Fn);
-                ARENA_GET(child.nchild, u8, Fn);
-                hipLaunchKernelGGL(node_kernel, grid_for(slots), dim3(256), 0, st, slots, flag, newidx, nTslot, mleft_slot, child.parent, child.sym,
-                                   nT[nxt], mleft[nxt], slot_of[nxt]);
-                for (int s = 0; s < nlocal; ++s) {
-                    const P* cf = reinterpret_cast<const P*>(x.base + (u64)rank * bpr) + (size_t)s * slots;
-                    hipLaunchKernelGGL((copy_kernel<P>), grid_for(slots), dim3(256), 0, st, slots, Fcap, flag, newidx, cf, tmp[s], rec[nxt][s]);
-                }
-                if (stream_mode) {
+                child.slot = arena.get<u32>(Fn);  // same address as new_slot
+                if (stream_mode) {  // freq / left char of every node are retained for the wire stream
                     P* fq;
+                    u8* lf;
                     ARENA_GET(fq, P, Fn);
+                    ARENA_GET(lf, u8, Fn);
+                    DSM_HIP(hipMemcpyAsync(fq, stage_freq, (size_t)Fn * sizeof(P), hipMemcpyDeviceToDevice, st));
+                    DSM_HIP(hipMemcpyAsync(lf, stage_left, (size_t)Fn, hipMemcpyDeviceToDevice, st));
                     child.freq = fq;
-                    ARENA_GET(child.left, u8, Fn);
-                    const P* cf = reinterpret_cast<const P*>(x.base);
-                    const u8* cl = x.base + (u64)nlocal * slots * sizeof(P);
-                    hipLaunchKernelGGL((keep_kernel<P>), grid_for(slots), dim3(256), 0, st, slots, flag, newidx, cf, cl, fq, child.left);
+                    child.left = lf;
                 }
+                ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
                 if (exact_order)
-                    hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], flag, newidx, order[nxt]);
+                    hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.firstchild, order[nxt]);
             }
             // ---- output predicates for the nodes of THIS level (their children are known now) -----
             if (!stream_mode && depth >= 1) {
@@ -1052,21 +1161,23 @@ class Engine {
                 fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
                 fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = exact_order ? 1u : 0u;
                 Xchg xp = xview(xcur ^ 1, prev_slots, prev_bpr);
-                ARENA_GET(me.cand_flag, u32, F);
-                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, slot_of[cur], nT[cur], mleft[cur], me.nchild, samechild,
-                                   me.cand_flag, cand_pairs);
-                exclusive_scan<u32, u32>(me.cand_flag, cand_idx, F, scan_tmp, d_totals, st);
-                exclusive_scan<u32, u32>(cand_pairs, cand_poff_node, F, scan_tmp, d_totals + 1, st);
-                if (int rc = read_totals(2)) return rc;
-                me.ncand = h_totals[0];
-                me.npairs = h_totals[1];
+                ARENA_GET(me.cand_flag, u8, F);
+                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], mleft[cur], me.firstchild, samechild,
+                                   me.cand_flag, cand_key);
+                exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
+                DSM_HIP(hipMemcpyAsync(h_totals + 16, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+                DSM_HIP(hipStreamSynchronize(st));
+                u64 tot = 0;
+                memcpy(&tot, h_totals + 16, sizeof tot);
+                me.ncand = (u32)(tot & 0xFFFFFFFFu);
+                me.npairs = (u32)(tot >> 32);
                 if (me.ncand) {
                     ARENA_GET(me.cand_node, u32, me.ncand);
                     ARENA_GET(me.cand_poff, u32, me.ncand);
                     ARENA_GET(me.ids, u32, me.npairs);
                     ARENA_GET(me.freqs, u64, me.npairs);
-                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, slot_of[cur], nT[cur], order[cur], me.cand_flag, cand_idx,
-                                       cand_poff_node, me.cand_node, me.cand_poff, me.ids, me.freqs);
+                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], me.cand_flag, cand_keyscan,
+                                       me.cand_node, me.cand_poff, me.ids, me.freqs);
                 }
                 stats.candidates += me.ncand;
             }
@@ -1093,12 +1204,11 @@ class Engine {
         float ms = 0;
         DSM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         stats.device_ms += ms;
-        for (auto& pr : evpairs) {
+        float expand_ms = 0;
+        for (size_t k = 0; k + 1 < nev; k += 2) {
             float t = 0;
-            DSM_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+            DSM_HIP(hipEventElapsedTime(&t, evpool[k], evpool[k + 1]));
             expand_ms += t;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
         }
         stats.expand_ms += expand_ms;
         u64 hc[4] = {0, 0, 0, 0};
@@ -1114,7 +1224,6 @@ class Engine {
         lines_fetched += hc[3];
         return 0;
     }
-    u64 lines_fetched = 0;
 
     // ---- mine: post-order ranks of the candidates, tuple assembly, exact entropy on the host ------
     int finish_mine(std::vector<LevelHost>& L, u32 nlev, dsm_tuple_sink sink, void* ctx) {
@@ -1127,8 +1236,7 @@ class Engine {
         for (u32 l = nlev; l-- > 1;) {
             ARENA_GET(L[l].sub, u32, L[l].n);
             const u32* child_sub = l + 1 < nlev ? L[l + 1].sub : nullptr;
-            hipLaunchKernelGGL((up_kernel<u32, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, L[l].nchild, child_sub,
-                               L[l].sub);
+            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
         }
         // top-down: start offsets, two rolling arrays
         u32 *t_level, *t_cidx;
@@ -1143,7 +1251,7 @@ class Engine {
         for (u32 l = 0; l + 1 < nlev; ++l) {
             u32* s_cur = startbuf[l & 1];
             u32* s_next = startbuf[(l + 1) & 1];
-            hipLaunchKernelGGL((down_kernel<u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l].nchild, L[l + 1].sub, s_next);
+            hipLaunchKernelGGL((down_kernel<u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l + 1].sub, s_next);
             if (L[l + 1].ncand)
                 hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, s_next, L[l + 1].sub, l + 1,
                                    t_level, t_cidx);
@@ -1151,7 +1259,7 @@ class Engine {
         // tuple sizes -> offsets
         std::vector<LevelDev> lv(nlev);
         for (u32 l = 0; l < nlev; ++l) {
-            lv[l].parent = L[l].parent; lv[l].sym = L[l].sym; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff;
+            lv[l].slot = L[l].slot; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff;
             lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = L[l].ncand; lv[l].npairs = L[l].npairs;
         }
         LevelDev* d_lv;
@@ -1169,7 +1277,8 @@ class Engine {
         exclusive_scan<u32, u32>(npair, pair_off, nt, stmp, d_totals + 1, st);
         DSM_HIP(hipMemcpyAsync(path_off + nt, d_totals, sizeof(u32), hipMemcpyDeviceToDevice, st));
         DSM_HIP(hipMemcpyAsync(pair_off + nt, d_totals + 1, sizeof(u32), hipMemcpyDeviceToDevice, st));
-        if (int rc = read_totals(2)) return rc;
+        DSM_HIP(hipMemcpyAsync(h_totals, d_totals, 2 * sizeof(u32), hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipStreamSynchronize(st));
         const u64 path_bytes = h_totals[0], npairs = h_totals[1];
         char* d_paths;
         u32* d_ids;
@@ -1197,7 +1306,6 @@ class Engine {
         emitter.submit();
         return 0;
     }
-    Emitter emitter;
 
     // wait for the emitter and fold its counters into stats
     int finish_emits() {
@@ -1222,27 +1330,25 @@ class Engine {
             ARENA_GET(L[l].off, u64, L[l].n);
         }
         for (u32 l = nlev; l-- > 0;)  // subtree node counts
-            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild, L[l].nchild,
+            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild,
                                l + 1 < nlev ? L[l + 1].sz : nullptr, L[l].sz);
         {  // pre-order numbers: pre(child_k) = pre(v) + 1 + sum sz(earlier siblings); root pre = -1
             u64 m1 = ~0ull;
             DSM_HIP(hipMemcpyAsync(L[0].pre, &m1, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l].nchild, L[l + 1].sz,
-                                   L[l + 1].pre);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l + 1].sz, L[l + 1].pre);
         }
         for (u32 l = 1; l < nlev; ++l)
             hipLaunchKernelGGL((stream_own_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, (const P*)L[l].freq, L[l].pre, L[l].sz, L[l].own);
         DSM_HIP(hipMemsetAsync(L[0].own, 0, 8, st));
         for (u32 l = nlev; l-- > 0;)  // subtree bytes
-            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild, L[l].nchild,
+            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild,
                                l + 1 < nlev ? L[l + 1].bytes : nullptr, L[l].bytes);
         {  // byte offsets: off(child_k) = off(v) + 2 + sum bytes(earlier siblings); root off = -2
             u64 m2 = ~0ull - 1;
             DSM_HIP(hipMemcpyAsync(L[0].off, &m2, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l].nchild, L[l + 1].bytes,
-                                   L[l + 1].off);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l + 1].bytes, L[l + 1].off);
         }
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
@@ -1250,13 +1356,13 @@ class Engine {
         u8* d_out;
         ARENA_GET(d_out, u8, total);
         for (u32 l = 1; l < nlev; ++l)
-            hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].sym, (const P*)L[l].freq, L[l].left, L[l].pre,
+            hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].slot, (const P*)L[l].freq, L[l].left, L[l].pre,
                                L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
         DSM_HIP(hipGetLastError());
         // deliver in pieces through a pinned staging buffer
         const size_t PIECE = 32u << 20;
-        u8* h_piece = nullptr;
-        DSM_HIP(hipHostMalloc((void**)&h_piece, PIECE));
+        if (int rc = stream_pin.ensure(PIECE)) return rc;
+        u8* h_piece = (u8*)stream_pin.p;
         int rc = 0;
         for (u64 o = 0; o < total && !rc; o += PIECE) {
             size_t nb = (size_t)((total - o) < PIECE ? (total - o) : PIECE);
@@ -1265,11 +1371,10 @@ class Engine {
             if (e != hipSuccess) { rc = fail(DSM_E_HIP, hipGetErrorString(e)); break; }
             if (sink && sink(ctx, h_piece, nb)) rc = fail(DSM_E_SINK, "byte sink failed");
         }
-        (void)hipHostFree(h_piece);
         return rc;
     }
+    PinBuf stream_pin;
 };
-
 
 static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
     if (p && p->wide) return true;

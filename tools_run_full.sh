@@ -1,4 +1,11 @@
 set -e
+R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/bench_prof.log 2>&1
-tail -c 400 $GRAFT_REPO_ROOT/gpurun_out/bench_prof.log
+$R/tools/gather_calib 4096 268435456 64 | tee $R/gpurun_out/calib_plain.txt
+$R/tools/gather_calib 4096 134217728 128 | tee -a $R/gpurun_out/calib_plain.txt
+rocprofv3 -L 2>/dev/null | grep -i -E "FETCH_SIZE|WRITE_SIZE|TCC_EA0_RDREQ|TCC_HIT|TCC_MISS|TCC_REQ" | head -20 > $R/gpurun_out/counters.txt || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_calib64 -- $R/tools/gather_calib 4096 268435456 64 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_calib128 -- $R/tools/gather_calib 4096 134217728 128 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_write.log 2>&1
+ls $R/gpurun_out/pmc_fetch/*/ | head
