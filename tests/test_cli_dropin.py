@@ -1,0 +1,68 @@
+"""Drop-in executables on the GPU box: our client against the UNMODIFIED reference metaserver (oracle/_ref binary,
+which travels with the repo), and the fused dsm_node driver against the reference server's golden stdout."""
+import os
+import socket
+import subprocess
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dsm-framework_amd", "host")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_dsm_node_prints_reference_tuples(golden):
+    names = golden.manifest["sets"]["toy3"]["names"]
+    fmis = [golden.fmi("toy3", n) for n in names]
+    out = subprocess.run([os.path.join(HOST, "dsm_node"), "-E", "2.0", "-f", "2", "-p", "A,GT,TTG"] + fmis, check=True,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+    assert out == b"".join(golden.server_out("toy3", "default", p) for p in ["A", "GT", "TTG"])
+    # mandatory -E like the reference server (metaserver.cpp:582-586)
+    r = subprocess.run([os.path.join(HOST, "dsm_node"), "-p", "A"] + fmis, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"expecting parameter --emax" in r.stderr
+
+
+def test_check_mode(golden):
+    r = subprocess.run([os.path.join(HOST, "metaenumerate_hip"), "--check", golden.fmi("toy3", "toy-1")], input=b"localhost 5000 A\n",
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"OK" in r.stderr and b"n = 102000, total = 102000" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "metaserver")), reason="oracle/_ref/metaserver not present")
+def test_our_client_feeds_the_unmodified_reference_server(golden, tmp_path):
+    names = golden.manifest["sets"]["toy3"]["names"]
+    prefixes = ["C", "AC", "T"]
+    procs, hosts = [], ""
+    for p in prefixes:
+        port = _free_port()
+        out = open(tmp_path / ("out." + p), "wb")
+        pr = subprocess.Popen([os.path.join(REF, "metaserver"), "-p", str(port), "-E", "2.0"], stdin=subprocess.PIPE, stdout=out,
+                              stderr=subprocess.DEVNULL)
+        pr.stdin.write(("\n".join(names) + "\n").encode())
+        pr.stdin.close()
+        procs.append((p, pr, out))
+        hosts += "127.0.0.1 %d %s\n" % (port, p)
+    time.sleep(0.5)
+    clients = []
+    for n in names:
+        c = subprocess.Popen([os.path.join(HOST, "metaenumerate_hip"), "--fmin", "2", golden.fmi("toy3", n)], stdin=subprocess.PIPE,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        c.stdin.write(hosts.encode())
+        c.stdin.close()
+        clients.append(c)
+    for c in clients:
+        assert c.wait(timeout=300) == 0, c.stderr.read()
+    for p, pr, out in procs:
+        assert pr.wait(timeout=120) == 0
+        out.close()
+        assert open(tmp_path / ("out." + p), "rb").read() == golden.server_out("toy3", "default", p), p
