@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rlen", type=int, default=100)
     ap.add_argument("--genome", type=int, default=50_000_000)
     ap.add_argument("--sub-rate", type=float, default=0.005)
-    ap.add_argument("--prefix-len", type=int, default=1)
+    ap.add_argument("--prefix-len", type=int, default=-1, help="k-mer prefix length of the chunks; default 1 (N=1) / 2 (N>1)")
     ap.add_argument("--fmin", type=int, default=10)
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
@@ -119,25 +119,21 @@ def main():
 
     path, build_s = build_index(args, rank, dev)
     ix = pydsm.Index(path, device=local)
-    prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=args.prefix_len)] if args.prefix_len > 0 else [""]
+    plen = args.prefix_len if args.prefix_len >= 0 else (1 if world == 1 else 2)  # >= world prefixes so every rank owns some output
+    prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
     pmin = 1 if world == 1 else 2
 
-    # exchange buffers owned by torch so that torch.distributed (RCCL) can all-gather them in place
+    # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
+    # one collective per frontier level, nothing else on the data path
     allgather = None
     exchange = None
     if world > 1:
-        xbytes = 1 << 30
-        send = torch.empty(xbytes, dtype=torch.uint8, device=dev)
-        recv = torch.empty(2 * xbytes * world, dtype=torch.uint8, device=dev)
-
-        def allgather(sp, rp, nbytes, stream):  # one RCCL all-gather per frontier level
-            off = rp - recv.data_ptr()
-            assert sp == send.data_ptr() and off in (0, xbytes * world)
-            dist.all_gather_into_tensor(recv[off: off + nbytes * world], send[:nbytes])
-        exchange = (send.data_ptr(), recv.data_ptr(), xbytes)
+        from pydsm.dist import Exchange
+        ex = Exchange(1 << 30, world, dev)
+        allgather, exchange = ex.allgather, ex.params()
     stream = torch.cuda.current_stream().cuda_stream
     miner = pydsm.Miner([ix], fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
-                        exchange=exchange, stream=stream)
+                        exchange=exchange, stream=stream, emit_owner_only=world > 1)
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
            "device_ms": 0.0, "host_ms": 0.0, "cand": 0}
@@ -188,7 +184,7 @@ def main():
         if os.path.exists(tj):
             try:
                 tinfo = json.load(open(tj))
-                if tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == args.prefix_len and tinfo.get("gpus") == args.gpus:
+                if tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == plen and tinfo.get("gpus") == args.gpus:
                     traffic = tinfo.get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None

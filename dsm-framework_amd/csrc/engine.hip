@@ -1013,7 +1013,7 @@ class Engine {
     }
 
     // Runs one prefix.  mine: tuples to `tsink` (through the emitter thread); stream: wire bytes to `bsink`.
-    int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx) {
+    int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx, bool emit = true) {
         const std::string prefix = prefix_c ? prefix_c : "";
         for (char ch : prefix)
             if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
@@ -1156,7 +1156,7 @@ class Engine {
                     hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.firstchild, order[nxt]);
             }
             // ---- output predicates for the nodes of THIS level (their children are known now) -----
-            if (!stream_mode && depth >= 1) {
+            if (!stream_mode && emit && depth >= 1) {
                 FilterArgs fa;
                 fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
                 fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = exact_order ? 1u : 0u;
@@ -1196,7 +1196,7 @@ class Engine {
         }
         const u32 nlev = (u32)L.size();  // levels 0..nlev-1, level l holds the nodes of depth l
 
-        int rc = stream_mode ? finish_stream(L, nlev, bsink, ctx) : finish_mine(L, nlev, tsink, ctx);
+        int rc = stream_mode ? finish_stream(L, nlev, bsink, ctx) : (emit ? finish_mine(L, nlev, tsink, ctx) : 0);
         if (rc) return rc;
 
         DSM_HIP(hipEventRecord(ev1, st));
@@ -1399,7 +1399,10 @@ struct MinerT : MinerBase {
     int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
         memset(&e.stats, 0, sizeof e.stats);
         int rc = 0;
-        for (int k = 0; k < n && !rc; ++k) rc = e.run(prefixes[k], ts, bs, ctx);
+        for (int k = 0; k < n && !rc; ++k) {
+            const bool mine = !e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank;
+            rc = e.run(prefixes[k], ts, bs, ctx, mine);
+        }
         int rc2 = e.finish_emits();
         if (out) *out = e.stats;
         return rc ? rc : rc2;

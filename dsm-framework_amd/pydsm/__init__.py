@@ -56,7 +56,7 @@ class Params(C.Structure):
                 ("pmax", C.c_uint32), ("mindepth", C.c_uint32), ("emin", C.c_double), ("emax", C.c_double),
                 ("world_size", C.c_uint32), ("rank", C.c_uint32), ("allgather", ALLGATHER), ("allgather_ctx", C.c_void_p),
                 ("exchange_send", C.c_void_p), ("exchange_recv", C.c_void_p), ("exchange_bytes", C.c_uint64),
-                ("arena_bytes", C.c_uint64), ("wide", C.c_uint32), ("stream", C.c_void_p)]
+                ("arena_bytes", C.c_uint64), ("wide", C.c_uint32), ("emit_owner_only", C.c_uint32), ("stream", C.c_void_p)]
 
 
 _lib = None
@@ -189,13 +189,14 @@ def default_params():
 
 
 def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes, wide,
-                 stream, keep):
+                 stream, keep, emit_owner_only=0):
     p = default_params()
     p.fmin, p.maxdepth, p.pmin, p.pmax, p.mindepth = fmin, maxdepth, pmin, pmax, mindepth
     p.emin, p.emax = emin, emax
     p.world_size, p.rank = world_size, rank
     p.arena_bytes = arena_bytes
     p.wide = wide
+    p.emit_owner_only = emit_owner_only
     p.stream = stream
     if allgather is not None:
         def _ag(ctx, s, r, n, st):
@@ -235,11 +236,12 @@ class Miner:
     stream_mode=False: .mine(prefix) -> (tuple text, Stats);  stream_mode=True (one index): .enumerate(prefix)."""
 
     def __init__(self, indexes, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0,
-                 world_size=1, rank=0, allgather=None, exchange=None, arena_bytes=0, wide=0, stream=None, stream_mode=False):
+                 world_size=1, rank=0, allgather=None, exchange=None, arena_bytes=0, wide=0, stream=None, stream_mode=False,
+                 emit_owner_only=False):
         self._keep = []
         self.indexes = list(indexes)
         p = _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes,
-                         wide, stream, self._keep)
+                         wide, stream, self._keep, 1 if emit_owner_only else 0)
         hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
         self.h = C.c_void_p()
         _check(lib().dsm_miner_create(hs, len(indexes), C.byref(p), 1 if stream_mode else 0, C.byref(self.h)))

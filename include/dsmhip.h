@@ -158,6 +158,8 @@ typedef struct dsm_params {
     uint64_t exchange_bytes;
     uint64_t arena_bytes;    /* device scratch budget; 0 = pick from free memory */
     uint32_t wide;           /* 1 = force 64-bit positions (all ranks must agree); 0 = from local index sizes */
+    uint32_t emit_owner_only;/* multi-rank dsm_miner_mine_many: prefix k is filtered and emitted only by rank k % world_size
+                                (every rank still expands its own samples for every prefix); 0 = every rank emits everything */
     void* stream;
 } dsm_params;
 

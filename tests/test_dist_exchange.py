@@ -80,6 +80,14 @@ def _gpu_worker(rank, world, port, q, fmis, prefixes, kw):
         for p in prefixes:
             text, st = m.mine(p)
             out.append((p, text, st.reported, st.union_nodes, st.pair_order_exact))
+    # owner-only emission: prefix k is emitted by rank k % world, everybody expands everything
+    with pydsm.Miner(idx, world_size=world, rank=rank, allgather=ex.allgather, exchange=ex.params(), emit_owner_only=True, **kw) as m:
+        parts = []
+
+        def on_batch(b):
+            parts.append(int(b.ntuples))
+        text, st = m.mine_many(prefixes, on_batch=on_batch)
+        out.append(("owner", text, st.reported, st.union_nodes, st.pair_order_exact))
     q.put((rank, out, ex.calls))
     for ix in idx:
         ix.close()
@@ -111,9 +119,12 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
     for rank, out, calls in res:
         assert calls > 0
         for p, text, rep, union, exact in out:
-            if p in ("A", "GT", "C") and (setname, p) != ("five", "GT"):
-                assert text == golden.server_out(setname, cfg, p), (rank, p)
             assert exact == 1
+            if p == "owner":
+                mine = b"".join(golden.server_out(setname, cfg, q) for k, q in enumerate(prefixes) if k % world == rank)
+                assert text == mine, (rank, "owner-only")
+                continue
+            assert text == golden.server_out(setname, cfg, p), (rank, p)
             reported.setdefault(p, []).append(rep)
     # per-rank `reported` is that rank's own sample: the sum equals the oracle's client total
     oidx = [orc.Index(f) for f in fmis]

@@ -1,0 +1,91 @@
+"""Parity at BASELINE.json's full size (configs[1]: 10^7 reads x 100 bp, n = 2.02e9), through properties that do not
+need the oracle to enumerate the whole trie:
+  * --check: the LF intervals of all symbols tile [0, n)                       (metaenumerate.cpp:93-127)
+  * random 8-mer prefixes of the FULL index: GPU tuples / wire bytes == oracle's, byte for byte
+  * a pass over one-letter prefixes: every emitted node is a union node (d = 1), tuples <= candidates,
+    counters per node match the reference's cost model, and stream mode reports the same node count
+Set DSM_FULLSIZE_READS to shrink it (default 10000000)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    import pydsm
+    from pydsm import builder
+    reads = int(os.environ.get("DSM_FULLSIZE_READS", "10000000"))
+    genome = reads * 5
+    d = os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "sample-0.s42_r%d_l100_g%d_e0.005.fmi" % (reads, genome))
+    if not os.path.exists(path):
+        codes = builder.synth_reads(42, reads, 100, genome, 0.005, device="cuda")
+        builder.build_from_codes(codes, path + ".tmp")
+        del codes
+        torch.cuda.empty_cache()
+        os.replace(path + ".tmp", path)
+    ix = pydsm.Index(path)
+    yield pydsm, ix, path, reads
+    ix.close()
+
+
+def test_check_and_random_prefixes_against_oracle(big):
+    import orc
+    pydsm, ix, path, reads = big
+    assert ix.n == reads * 202
+    assert ix.check() == ix.n
+    o = orc.Index(path)
+    rng = np.random.default_rng(2026)
+    # LF on random positions, every live symbol
+    Cc, cnt, bits, code = o.meta()
+    syms = [int(s) for s in np.nonzero(cnt)[0]]
+    pos = np.concatenate([np.array([0xFFFFFFFFFFFFFFFF, 0, ix.n - 1], np.uint64), rng.integers(0, ix.n, 200000).astype(np.uint64)])
+    cs = rng.choice(syms, len(pos)).astype(np.uint8)
+    assert (ix.lf_batch(cs, pos) == o.lf_batch(cs, pos)).all()
+    with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m, pydsm.Miner([ix], fmin=10, stream_mode=True) as sm:
+        for _ in range(6):
+            p = "".join(rng.choice(list("ACGT"), 8))
+            got, st = m.mine(p)
+            want, ost = orc.mine([o], [ix.name], [p], fmin=10, pmin=1, emax=2.0)
+            assert got == want, p
+            assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples) == ost[:5], p
+            wire, sst = sm.enumerate(p)
+            owire, _ = o.enumerate(ix.name, p, fmin=10)
+            assert wire == owire, p
+            assert sst.reported == st.reported
+    o.close()
+
+
+def test_whole_pass_invariants(big):
+    pydsm, ix, path, reads = big
+    seen = {"tuples": 0, "last": None, "ok": True}
+
+    def on_batch(b):
+        # post-order inside a prefix: a tuple's path is never a proper prefix of the NEXT tuple's path unless ... (children first)
+        n = int(b.ntuples)
+        seen["tuples"] += n
+        po = np.ctypeslib.as_array(b.path_off, shape=(n + 1,))
+        ent = np.ctypeslib.as_array(b.entropy, shape=(n,))
+        fr = np.ctypeslib.as_array(b.freqs, shape=(int(np.ctypeslib.as_array(b.pair_off, shape=(n + 1,))[-1]),))
+        seen["ok"] = seen["ok"] and bool((ent >= 0).all() and (ent <= 2.0).all() and (fr >= 10).all() and (np.diff(po) >= 1).all())
+
+    with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m:
+        _, st = m.mine_many(["A", "C", "G", "T"], text=False, on_batch=on_batch)
+    assert seen["ok"]
+    assert st.union_nodes == st.reported                      # d = 1: every union node is a node of the one sample
+    assert seen["tuples"] == st.tuples <= st.candidates
+    assert 10.0 < st.lf_steps / st.reported < 11.5            # reference cost model: ~10.8 LF and ~24.3 rank-ops per node
+    assert 23.0 < st.rank_ops / st.reported < 25.5
+    # the same pass as wire streams reports the same number of nodes
+    with pydsm.Miner([ix], fmin=10, stream_mode=True) as sm:
+        nb, sst = sm.enumerate("G", discard=True)
+    with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m:
+        _, gst = m.mine("G", text=False)
+    assert sst.reported == gst.reported and nb > 4 * sst.reported

@@ -198,3 +198,21 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
     assert e.value.code in (-28, -12)
     for ix in idx:
         ix.close()
+
+
+def test_64bit_position_path(golden, pydsm_mod):
+    """cfg 4 needs u64 positions (n > 2^32); the same kernels instantiated for u64 must give the same bytes."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    idx = [pydsm_mod.Index(golden.fmi("toy3", n)) for n in names]
+    for p in ["A", "GT"]:
+        got, st = pydsm_mod.mine(idx, p, fmin=2, emax=2.0, wide=1)
+        assert got == golden.server_out("toy3", "default", p)
+    with pydsm_mod.Miner([idx[0]], fmin=2, stream_mode=True, wide=1) as m:
+        for p in ["C", "ACGTACGTACGT"]:
+            got, _ = m.enumerate(p)
+            assert got == golden.stream("toy3", names[0], p)
+    with pydsm_mod.Miner([idx[0]], fmin=1, maxdepth=40, stream_mode=True, wide=1) as m:
+        got, _ = m.enumerate("G")
+        assert got == golden.stream("toy3", names[0], "G", "fmin1.M40")
+    for ix in idx:
+        ix.close()
