@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "scan.h"
+#include "setorder.h"
 
 namespace dsm {
 
@@ -230,6 +231,7 @@ __device__ __forceinline__ u8 x_left(const Xchg& x, u32 g, u64 slot) {
 // ---------------------------------------------------------------------------------------------
 // advance: union frontier of the next level.  A thread owns 8 consecutive slots = 2 parents.
 // ---------------------------------------------------------------------------------------------
+constexpr int MAX_LOCAL = 32;  // local indexes per process
 constexpr int ADV_SLOTS = 8;
 constexpr int ADV_TILE = 256 * ADV_SLOTS;
 
@@ -274,8 +276,8 @@ struct AdvanceOut {
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
     // per local sample record handles
-    u32* rp[8];
-    const u32* tpos[8];
+    u32* rp[MAX_LOCAL];
+    const u32* tpos[MAX_LOCAL];
     u32 nlocal, rank;
     // stream mode (d == 1)
     void* keep_freq;
@@ -394,13 +396,49 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
     }
 }
 
+// More than 13 samples: the sets rehash (13 -> 29 -> 59 -> ...) and ids share buckets, so the order is replayed with the
+// container model of setorder.h.  Orders are u16 arrays, d entries per node.
+template <typename P, int MAXD>
+__global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u16* __restrict__ order, const u32* __restrict__ firstchild,
+                                 u16* __restrict__ order_next) {
+    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= F) return;
+    const u32 cnt = nT[u];
+    const u16* ord = order + (size_t)u * x.d;
+    u8 mask[MAXD];
+    u16 ins[4][MAXD];
+    u16 loc[MAXD], tmp[MAXD];
+    u32 icnt[4] = {0, 0, 0, 0};
+    for (u32 k = 0; k < cnt; ++k) {  // round 1: every reader of the parent reads its first child
+        const u32 r = ord[k];
+        u32 m = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m |= (x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
+        mask[r] = (u8)m;
+        if (m) { int f = __ffs(m) - 1; ins[f][icnt[f]++] = (u16)r; }
+    }
+    u32 v = firstchild[u];
+    for (int i = 0; i < 4; ++i) {
+        if (!icnt[i]) continue;
+        set_iteration_order(ins[i], icnt[i], loc, tmp);
+        u16* dst = order_next + (size_t)v * x.d;
+        for (u32 k = 0; k < icnt[i]; ++k) dst[k] = loc[k];
+        ++v;
+        for (u32 k = 0; k < icnt[i]; ++k) {  // next round: this child's readers, in its iteration order
+            const u32 r = loc[k];
+            u32 m = mask[r] & ~((2u << i) - 1);
+            if (m) { int g = __ffs(m) - 1; ins[g][icnt[g]++] = (u16)r; }
+        }
+    }
+}
+
 struct FilterArgs {
     u32 F;
     u32 depth;
     u32 d;
     u32 pmin, pmax, mindepth;
     double emin, emax;
-    u32 exact_order;  // order[] valid (1 < d <= 13)
+    u32 exact_order;  // 0: d == 1; 1: nibble-packed order[] (d <= 13); 2: u16 order arrays (d > 13)
 };
 
 // output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
@@ -440,7 +478,7 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
 template <typename P>
 __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u64* __restrict__ order,
-                                  const u8* __restrict__ cand, const u64* __restrict__ keyscan,
+                                  const u16* __restrict__ order16, const u8* __restrict__ cand, const u64* __restrict__ keyscan,
                                   u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= a.F || !cand[v]) return;
@@ -449,11 +487,18 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ 
     cand_node[k] = v;
     cand_poff[k] = o;
     const u64 j = slot_of[v];
-    if (a.exact_order) {
+    if (a.exact_order == 1) {
         const u64 ord = order[v];
         const u32 cnt = nT[v];
         for (u32 q = 0; q < cnt; ++q) {
             u32 g = (u32)((ord >> (4 * q)) & 15);
+            ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
+        }
+    } else if (a.exact_order == 2) {
+        const u16* ord = order16 + (size_t)v * a.d;
+        const u32 cnt = nT[v];
+        for (u32 q = 0; q < cnt; ++q) {
+            u32 g = ord[q];
             ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
         }
     } else {
@@ -856,6 +901,7 @@ class Engine {
     u16* nT[2] = {nullptr, nullptr};
     u8 *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
     u64* order[2] = {nullptr, nullptr};
+    u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_key = nullptr, *cand_keyscan = nullptr, *scan_tmp64 = nullptr;
     u64* d_counters = nullptr;
     u32* d_alloc = nullptr;   // [nlocal] compact-record allocation counters
@@ -898,7 +944,7 @@ class Engine {
         rank = world > 1 ? (int)p.rank : 0;
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
-        if (n > 8) return fail(DSM_E_INVAL, "at most 8 local indexes per process");
+        if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 32 local indexes per process");
         d = (u32)(world * nlocal);
         if (d > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
         st = (hipStream_t)p.stream;
@@ -925,7 +971,7 @@ class Engine {
         u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4 * 4)   // rec x2, rp x2, tpos
                    + (u64)nlocal * 4 * (sizeof(P) + 1)                         // send
                    + 2ull * d * 4 * (sizeof(P) + 1)                            // recv x2
-                   + 2 * (2 + 1 + 8) + 1 + 16 + 64;
+                   + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0);
         u64 fc = budget / 3 / perF;
         if (fc > (1u << 28)) fc = 1u << 28;
         if (fc > fbound) fc = fbound;
@@ -965,6 +1011,9 @@ class Engine {
             if (int rc = dalloc(mleft[k], Fcap)) return rc;
             if (int rc = dalloc(order[k], Fcap)) return rc;
         }
+        if (d > 13)
+            for (int k = 0; k < 2; ++k)
+                if (int rc = dalloc(order16[k], (size_t)Fcap * d)) return rc;
         if (int rc = dalloc(samechild, Fcap)) return rc;
         if (stream_mode) {
             if (int rc = dalloc(stage_freq, Fcap)) return rc;
@@ -974,7 +1023,7 @@ class Engine {
         if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
-        if (int rc = dalloc(d_alloc, 8)) return rc;
+        if (int rc = dalloc(d_alloc, MAX_LOCAL)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 64 * sizeof(u32)));
@@ -1053,13 +1102,20 @@ class Engine {
             L.push_back(root);
             u16 rootT = (u16)d;
             DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
-            // root reader set: ids inserted 0..d-1, iterated in reverse (d <= 13)
-            u64 ord = 0;
-            for (u32 k = 0; k < d && k < 16; ++k) ord |= (u64)(d - 1 - k) << (4 * k);
-            DSM_HIP(hipMemcpyAsync(order[0], &ord, sizeof(u64), hipMemcpyHostToDevice, st));
+            // root reader set: ids inserted 0..d-1 (metaserver.cpp:736-739)
+            std::vector<u16> seq(d), ro(d + 1), tmp(d + 1);
+            for (u32 k = 0; k < d; ++k) seq[k] = (u16)k;
+            set_iteration_order(seq.data(), d, ro.data(), tmp.data());
+            if (d <= 13) {
+                u64 ord = 0;
+                for (u32 k = 0; k < d; ++k) ord |= (u64)ro[k] << (4 * k);
+                DSM_HIP(hipMemcpyAsync(order[0], &ord, sizeof(u64), hipMemcpyHostToDevice, st));
+            } else {
+                DSM_HIP(hipMemcpyAsync(order16[0], ro.data(), (size_t)d * sizeof(u16), hipMemcpyHostToDevice, st));
+            }
         }
-        const bool exact_order = d >= 2 && d <= 13;
-        stats.pair_order_exact = (d <= 13) ? 1 : 0;
+        const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);
+        stats.pair_order_exact = 1;
 
         int cur = 0;      // ping-pong index of the current level (rec, rp, nT, mleft, order)
         int xcur = 0;     // exchange buffer that will receive the current level's children
@@ -1083,7 +1139,7 @@ class Engine {
                 ea.allowed = depth >= prm.maxdepth ? 0u : 15u;  // EnumerateQuery.cpp:153
                 ea.symbol_phase = 1;
             }
-            DSM_HIP(hipMemsetAsync(d_alloc, 0, 8 * sizeof(u32), st));
+            DSM_HIP(hipMemsetAsync(d_alloc, 0, MAX_LOCAL * sizeof(u32), st));
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             DSM_HIP(hipEventRecord(ea0, st));
@@ -1129,7 +1185,7 @@ class Engine {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
             }
             DSM_HIP(hipMemcpyAsync(h_totals, d_totals, sizeof(u32), hipMemcpyDeviceToHost, st));
-            DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, 8 * sizeof(u32), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, MAX_LOCAL * sizeof(u32), hipMemcpyDeviceToHost, st));
             DSM_HIP(hipStreamSynchronize(st));
             const u32 Fn = h_totals[0];
             for (int s = 0; s < nlocal; ++s)
@@ -1152,23 +1208,27 @@ class Engine {
                     child.left = lf;
                 }
                 ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
-                if (exact_order)
+                if (order_mode == 1)
                     hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.firstchild, order[nxt]);
+                else if (order_mode == 2 && d <= 64)
+                    hipLaunchKernelGGL((order_big_kernel<P, 64>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
+                else if (order_mode == 2)
+                    hipLaunchKernelGGL((order_big_kernel<P, 273>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
             }
             // ---- output predicates for the nodes of THIS level (their children are known now) -----
             if (!stream_mode && emit && depth >= 1) {
                 FilterArgs fa;
                 fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
-                fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = exact_order ? 1u : 0u;
+                fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
                 Xchg xp = xview(xcur ^ 1, prev_slots, prev_bpr);
                 ARENA_GET(me.cand_flag, u8, F);
                 hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], mleft[cur], me.firstchild, samechild,
                                    me.cand_flag, cand_key);
                 exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-                DSM_HIP(hipMemcpyAsync(h_totals + 16, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+                DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
                 DSM_HIP(hipStreamSynchronize(st));
                 u64 tot = 0;
-                memcpy(&tot, h_totals + 16, sizeof tot);
+                memcpy(&tot, h_totals + 48, sizeof tot);
                 me.ncand = (u32)(tot & 0xFFFFFFFFu);
                 me.npairs = (u32)(tot >> 32);
                 if (me.ncand) {
@@ -1176,7 +1236,7 @@ class Engine {
                     ARENA_GET(me.cand_poff, u32, me.ncand);
                     ARENA_GET(me.ids, u32, me.npairs);
                     ARENA_GET(me.freqs, u64, me.npairs);
-                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], me.cand_flag, cand_keyscan,
+                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], order16[cur], me.cand_flag, cand_keyscan,
                                        me.cand_node, me.cand_poff, me.ids, me.freqs);
                 }
                 stats.candidates += me.ncand;

@@ -12,6 +12,7 @@ Fixture sets (see tests/golden/MANIFEST.json, written by this script):
   toy3   3 samples x 1000 reads x 50 bp, 6.6 kbp genome (order-6 de Bruijn + random); fmin 2; prefixes A C G T and AC GT TTG
   toyN   1 sample with N / lower-case / IUPAC symbols (normalisation + 7-symbol alphabet)
   deep1  toy3 sample 1, --fmin 1 -M 40 (followOneBranch path), prefixes A C G T
+  many30 30 tiny samples, --fmin 3 -M 14 (more than 13 readers: std::unordered_set rehashes, ids share buckets)
   five   5 samples x 1600..2200 reads x 60 bp, 4.7 kbp genome, default --fmin 10 (cfg-1 plumbing, scaled down)
 """
 import gzip
@@ -271,6 +272,26 @@ def main():
         put(os.path.join(HERE, "five", "server.default.%s.txt.gz" % p), d)
     manifest["sets"]["five"] = {"names": names5, "fmin": 10, "prefixes": prefixes,
                                 "server_cfgs": {"default": ["-E", "2.0"]}}
+
+    # ---------------- many30: 30 samples (reader sets rehash 13 -> 29 -> 59 buckets) ----------------
+    rng = np.random.default_rng(30)
+    genome30 = np.concatenate([de_bruijn(6), rng.integers(0, 4, 400).astype(np.uint8)])
+    names30, fmis30 = [], []
+    for s in range(30):
+        reads = synth_reads(rng, genome30, 700 + 10 * s, 40, 0.01)
+        name = "m%02d" % s
+        fa = os.path.join(work, name + ".fasta")
+        write_fasta(fa, reads)
+        fmi = run_builder(fa)
+        names30.append(name)
+        fmis30.append(fmi)
+        put(os.path.join(HERE, "many30", name + ".fasta.fmi.gz"), open(fmi, "rb").read())
+    cfgs30 = {"default": ["-E", "5.0"], "p3": ["-E", "4.9", "-e", "1.0", "-P", "3", "--pmax", "20", "-m", "7"]}
+    for cfg, sargs in cfgs30.items():
+        outs = run_servers(names30, fmis30, ["AC", "G"], ["--fmin", "3", "-M", "14"], sargs)
+        for p, d in outs.items():
+            put(os.path.join(HERE, "many30", "server.%s.%s.txt.gz" % (cfg, p)), d)
+    manifest["sets"]["many30"] = {"names": names30, "fmin": 3, "maxdepth": 14, "prefixes": ["AC", "G"], "server_cfgs": cfgs30}
 
     manifest["glibc"] = os.confstr("CS_GNU_LIBC_VERSION")
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:

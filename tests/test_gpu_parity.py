@@ -216,3 +216,16 @@ def test_64bit_position_path(golden, pydsm_mod):
         assert got == golden.stream("toy3", names[0], "G", "fmin1.M40")
     for ix in idx:
         ix.close()
+
+
+def test_thirty_samples_exact_pair_order(golden, pydsm_mod):
+    """d = 30 > 13: the reference's reader sets rehash and ids share buckets; pair order and FP summation order must still match."""
+    m = golden.manifest["sets"]["many30"]
+    idx = [pydsm_mod.Index(golden.fmi("many30", n)) for n in m["names"]]
+    for cfg, args in m["server_cfgs"].items():
+        for p in m["prefixes"]:
+            got, st = pydsm_mod.mine(idx, p, fmin=m["fmin"], maxdepth=m["maxdepth"], **server_args_to_kw(args))
+            assert got == golden.server_out("many30", cfg, p), (cfg, p)
+            assert st.pair_order_exact == 1
+    for ix in idx:
+        ix.close()
