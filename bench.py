@@ -110,11 +110,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)  # rehearsals with more ranks than cards (DSM_BENCH_BACKEND=gloo) share a card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import pydsm
 
     path, build_s = build_index(args, rank, dev)
@@ -129,7 +135,7 @@ def main():
     exchange = None
     if world > 1:
         from pydsm.dist import Exchange
-        ex = Exchange(1 << 30, world, dev)
+        ex = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))), world, dev)
         allgather, exchange = ex.allgather, ex.params()
     stream = torch.cuda.current_stream().cuda_stream
     miner = pydsm.Miner([ix], fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
@@ -157,6 +163,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1:
+        import atexit
+        atexit.register(lambda: print("TRACE rank %d: %s" % (rank, ex.trace[:60]), file=sys.stderr, flush=True))
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -165,7 +174,7 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(tot["reported"])], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(tot["reported"])], dtype=torch.float64, device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

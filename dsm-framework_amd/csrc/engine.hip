@@ -916,6 +916,7 @@ class Engine {
     std::vector<hipEvent_t> evpool;
     dsm_stats stats;
     u64 lines_fetched = 0;
+    u32 splits = 0;
     Emitter emitter;
 
     ~Engine() {
@@ -992,6 +993,13 @@ class Engine {
             if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
             if (world > 1) { if (int rc = dalloc(xsend, (size_t)bpr_cap)) return rc; }
         }
+        // every rank must take the same capacity decisions (a prefix that overflows is split on all ranks or on none):
+        // agree on the smallest frontier capacity through the host's all-gather
+        if (world > 1) {
+            u64 mine = Fcap, agreed = 0;
+            if (int rc = agree_min(mine, &agreed)) return rc;
+            Fcap = (u32)agreed;
+        }
         const u64 slots = (u64)Fcap * 4;
         for (int s = 0; s < nlocal; ++s) {
             P *a, *b;
@@ -1035,10 +1043,29 @@ class Engine {
         }
         u64 arena_b = budget > used ? budget - used : 0;
         if (arena_b < (64u << 20)) arena_b = 64u << 20;
+        if (world > 1) {
+            u64 agreed = 0;
+            if (int rc = agree_min(arena_b, &agreed)) return rc;
+            arena_b = agreed;
+        }
         if (int rc = dalloc(arena.base, arena_b)) return rc;
         arena.cap = arena_b;
         DSM_HIP(hipEventCreate(&ev0));
         DSM_HIP(hipEventCreate(&ev1));
+        return 0;
+    }
+
+    // min over ranks of one u64, through the exchange buffers and the host's all-gather callback
+    int agree_min(u64 mine, u64* out) {
+        u8* send = xsend;
+        DSM_HIP(hipMemcpyAsync(send, &mine, sizeof(u64), hipMemcpyHostToDevice, st));
+        if (prm.allgather(prm.allgather_ctx, send, xrecv[0], sizeof(u64), (void*)st)) return fail(DSM_E_SINK, "allgather callback failed");
+        std::vector<u64> all((size_t)world);
+        DSM_HIP(hipMemcpyAsync(all.data(), xrecv[0], (size_t)world * sizeof(u64), hipMemcpyDeviceToHost, st));
+        DSM_HIP(hipStreamSynchronize(st));
+        u64 m = all[0];
+        for (u64 v : all) m = v < m ? v : m;
+        *out = m;
         return 0;
     }
 
@@ -1062,7 +1089,17 @@ class Engine {
     }
 
     // Runs one prefix.  mine: tuples to `tsink` (through the emitter thread); stream: wire bytes to `bsink`.
-    int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx, bool emit = true) {
+    // emit_lo / emit_hi: only nodes with emit_lo <= depth <= emit_hi are filtered and emitted; expand_cap: nodes at that
+    // depth or deeper are not expanded.  Used when a prefix is split because a level did not fit (see MinerT::run_auto).
+    // seed / capture: reader-set iteration orders depend on the whole sibling structure above a node, so a sub-prefix
+    // run must start from the order its root had in the unsplit trie (captured by the shallow pass of the parent).
+    struct NodeOrder {
+        u32 depth = 0;
+        std::vector<u32> sym;               // capture: symbol of each node at `depth`
+        std::vector<std::vector<u16>> ord;  // capture: their orders; seed: ord[0]
+    };
+    int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx, bool emit = true, u32 emit_lo = 1,
+            u32 emit_hi = ~0u, u32 expand_cap = ~0u, const NodeOrder* seed = nullptr, NodeOrder* capture = nullptr) {
         const std::string prefix = prefix_c ? prefix_c : "";
         for (char ch : prefix)
             if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
@@ -1114,7 +1151,7 @@ class Engine {
                 DSM_HIP(hipMemcpyAsync(order16[0], ro.data(), (size_t)d * sizeof(u16), hipMemcpyHostToDevice, st));
             }
         }
-        const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);
+        const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);  // (declared before the level loop: used by seed/capture)
         stats.pair_order_exact = 1;
 
         int cur = 0;      // ping-pong index of the current level (rec, rp, nT, mleft, order)
@@ -1136,7 +1173,7 @@ class Engine {
                 ea.allowed = 1u << (q - bases);
                 ea.symbol_phase = 0;
             } else {
-                ea.allowed = depth >= prm.maxdepth ? 0u : 15u;  // EnumerateQuery.cpp:153
+                ea.allowed = (depth >= prm.maxdepth || depth >= expand_cap) ? 0u : 15u;  // EnumerateQuery.cpp:153
                 ea.symbol_phase = 1;
             }
             DSM_HIP(hipMemsetAsync(d_alloc, 0, MAX_LOCAL * sizeof(u32), st));
@@ -1215,8 +1252,39 @@ class Engine {
                 else if (order_mode == 2)
                     hipLaunchKernelGGL((order_big_kernel<P, 273>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
             }
+            if (Fn && order_mode && seed && depth + 1 == seed->depth) {  // the sub-prefix root keeps its order from the unsplit trie
+                const std::vector<u16>& so = seed->ord[0];
+                if (order_mode == 1) {
+                    u64 ord = 0;
+                    for (size_t k = 0; k < so.size(); ++k) ord |= (u64)so[k] << (4 * k);
+                    DSM_HIP(hipMemcpyAsync(order[nxt], &ord, sizeof(u64), hipMemcpyHostToDevice, st));
+                } else {
+                    DSM_HIP(hipMemcpyAsync(order16[nxt], so.data(), so.size() * sizeof(u16), hipMemcpyHostToDevice, st));
+                }
+            }
+            if (Fn && capture && depth + 1 == capture->depth) {
+                std::vector<u32> hs(Fn);
+                std::vector<u16> hn(Fn);
+                DSM_HIP(hipMemcpyAsync(hs.data(), child.slot, (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
+                DSM_HIP(hipMemcpyAsync(hn.data(), nT[nxt], (size_t)Fn * sizeof(u16), hipMemcpyDeviceToHost, st));
+                DSM_HIP(hipStreamSynchronize(st));
+                capture->sym.clear();
+                capture->ord.clear();
+                for (u32 v = 0; v < Fn; ++v) {
+                    capture->sym.push_back(hs[v] & 3);
+                    std::vector<u16> o(hn[v]);
+                    if (order_mode == 1) {
+                        u64 ord = 0;
+                        DSM_HIP(hipMemcpy(&ord, order[nxt] + v, sizeof(u64), hipMemcpyDeviceToHost));
+                        for (u32 k = 0; k < hn[v]; ++k) o[k] = (u16)((ord >> (4 * k)) & 15);
+                    } else if (order_mode == 2) {
+                        DSM_HIP(hipMemcpy(o.data(), order16[nxt] + (size_t)v * d, (size_t)hn[v] * sizeof(u16), hipMemcpyDeviceToHost));
+                    }
+                    capture->ord.push_back(o);
+                }
+            }
             // ---- output predicates for the nodes of THIS level (their children are known now) -----
-            if (!stream_mode && emit && depth >= 1) {
+            if (!stream_mode && emit && depth >= 1 && depth >= emit_lo && depth <= emit_hi) {
                 FilterArgs fa;
                 fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
                 fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
@@ -1296,6 +1364,10 @@ class Engine {
         for (u32 l = nlev; l-- > 1;) {
             ARENA_GET(L[l].sub, u32, L[l].n);
             const u32* child_sub = l + 1 < nlev ? L[l + 1].sub : nullptr;
+            if (!L[l].cand_flag) {  // level outside the emitted depth range: no candidates of its own
+                ARENA_GET(L[l].cand_flag, u8, L[l].n);
+                DSM_HIP(hipMemsetAsync(L[l].cand_flag, 0, L[l].n, st));
+            }
             hipLaunchKernelGGL((up_kernel<u32, u8>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
         }
         // top-down: start offsets, two rolling arrays
@@ -1455,15 +1527,43 @@ struct MinerT : MinerBase {
         const char* one[1] = {prefix};
         return run_many(one, 1, ts, bs, ctx, out);
     }
+    // A prefix whose trie does not fit the device buffers is split the way the reference scales: by longer prefixes.
+    // The four sub-prefixes emit everything deeper than the prefix itself; a shallow pass (children of the prefix only)
+    // then emits the prefix node and its ancestors, whose predicates need all four children (metaserver.cpp:416-417).
+    // Post-order is preserved: descendants first, in A,C,G,T order.  Collective-safe: every rank sees the same failure
+    // only if capacities agree, so ranks must use equal arena sizes.  (reported / union_nodes count the enforced path
+    // once per sub-run in that case.)
+    typedef typename Engine<P>::NodeOrder NodeOrder;
+    int run_auto(const std::string& prefix, dsm_tuple_sink ts, void* ctx, bool emit, u32 lo, const NodeOrder* seed) {
+        int rc = e.run(prefix.c_str(), ts, nullptr, ctx, emit, lo, ~0u, ~0u, seed);
+        if (rc != DSM_E_CAPACITY || prefix.size() >= 32) return rc;
+        ++e.splits;
+        const u32 k = (u32)prefix.size();
+        NodeOrder cap;  // shallow pass: the children of the prefix node with all four siblings visible -> their orders
+        cap.depth = k + 1;
+        rc = e.run(prefix.c_str(), ts, nullptr, ctx, false, lo, ~0u, k + 1, seed, &cap);
+        if (rc) return rc;
+        for (size_t q = 0; q < cap.sym.size(); ++q) {
+            NodeOrder sub;
+            sub.depth = k + 1;
+            sub.ord.push_back(cap.ord[q]);
+            rc = run_auto(prefix + "ACGT"[cap.sym[q]], ts, ctx, emit, k + 1, &sub);
+            if (rc) return rc;
+        }
+        return e.run(prefix.c_str(), ts, nullptr, ctx, emit, lo, k, k + 1, seed);
+    }
     // prefixes one after the other on the GPU; the host emits prefix k while prefix k+1 is being expanded
     int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
         memset(&e.stats, 0, sizeof e.stats);
         int rc = 0;
         for (int k = 0; k < n && !rc; ++k) {
             const bool mine = !e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank;
-            rc = e.run(prefixes[k], ts, bs, ctx, mine);
+            if (e.stream_mode) rc = e.run(prefixes[k], ts, bs, ctx, mine);
+            else rc = run_auto(prefixes[k] ? prefixes[k] : "", ts, ctx, mine, 1, nullptr);
         }
         int rc2 = e.finish_emits();
+        e.stats.splits = e.splits;
+        e.splits = 0;
         if (out) *out = e.stats;
         return rc ? rc : rc2;
     }
@@ -1471,12 +1571,10 @@ struct MinerT : MinerBase {
 
 template <typename P>
 static int mine_impl(dsm_index* const* idx, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
-    std::unique_ptr<Engine<P>> e(new Engine<P>());
-    int rc = e->init(idx, n, *p, false);
-    if (!rc) rc = e->run(p->prefix, sink, nullptr, ctx);
-    int rc2 = e->finish_emits();
-    if (stats) *stats = e->stats;
-    return rc ? rc : rc2;
+    std::unique_ptr<MinerT<P>> m(new MinerT<P>());
+    int rc = m->e.init(idx, n, *p, false);
+    if (rc) return rc;
+    return m->run(p->prefix, sink, nullptr, ctx, stats);
 }
 template <typename P>
 static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 maxdepth, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {

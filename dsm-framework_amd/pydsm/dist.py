@@ -19,6 +19,7 @@ class Exchange:
         self.recv = torch.zeros(2 * self.nbytes * self.world, dtype=torch.uint8, device=self.device)
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.calls = 0
+        self.trace = [] if __import__('os').environ.get('DSM_TRACE_EXCHANGE') else None
         self.bytes_moved = 0
 
     def params(self):
@@ -38,6 +39,8 @@ class Exchange:
         if nbytes > self.nbytes:
             raise ValueError("level larger than the exchange buffers")
         off = self.half(recv_ptr)
+        if self.trace is not None:
+            self.trace.append(int(nbytes))
         out = self.recv[off: off + nbytes * self.world]
         src = self.send[:nbytes]
         if self.backend == "nccl" or self.device.type == "cpu":

@@ -103,6 +103,7 @@ typedef struct dsm_stats {
     double device_ms;        /* HIP-event time of everything enqueued for the call */
     double host_ms;          /* host post-processing (exact entropy, tuple assembly) */
     uint64_t pair_order_exact; /* 1 when id:freq order and FP summation order follow the reference bit for bit */
+    uint64_t splits;         /* prefixes that were split into longer ones because a level did not fit the device buffers */
 } dsm_stats;
 
 /* ------------------------------------------------------------------------------------------------

@@ -192,10 +192,23 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
             assert got == golden.stream("toy3", names[1], p)
     with pytest.raises(pydsm_mod.DsmError):
         pydsm_mod.Miner(idx, stream_mode=True)
-    # a tiny arena must fail with the capacity error, not crash
+    # an arena too small for the frontier buffers is refused at creation
     with pytest.raises(pydsm_mod.DsmError) as e:
         pydsm_mod.mine(idx, "A", fmin=2, emax=2.0, arena_bytes=1 << 20)
     assert e.value.code in (-28, -12)
+    # a small one makes levels overflow: the prefix is split into longer ones and the output does not change
+    total_splits = 0
+    for arena in (3 << 20, 6 << 20):
+        for p in ("A", "GT", "T"):
+            got, st = pydsm_mod.mine(idx, p, fmin=2, emax=2.0, arena_bytes=arena)
+            assert got == golden.server_out("toy3", "default", p), (arena, p)
+            total_splits += st.splits
+    assert total_splits > 0
+    # stream mode does not split: it reports the capacity error
+    with pytest.raises(pydsm_mod.DsmError) as e:
+        with pydsm_mod.Miner([idx[0]], fmin=2, stream_mode=True, arena_bytes=2 << 20) as m:
+            m.enumerate("A")
+    assert e.value.code == -28
     for ix in idx:
         ix.close()
 
