@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
     ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
     return ap.parse_args()
 
@@ -57,7 +58,7 @@ def build_index(args, rank, dev):
     t0 = time.time()
     if not os.path.exists(path):
         codes = builder.synth_reads(42 + rank, args.reads, args.rlen, args.genome, args.sub_rate, device=dev,
-                                    private_frac=0.05 if args.gpus > 1 else 0.0)
+                                    private_frac=0.05 if args.gpus * args.nlocal > 1 else 0.0)
         builder.build_from_codes(codes, path + ".tmp")
         del codes
         torch.cuda.empty_cache()
@@ -123,11 +124,17 @@ def main():
             dist.init_process_group(backend)
     import pydsm
 
-    path, build_s = build_index(args, rank, dev)
-    ix = pydsm.Index(path, device=local)
+    paths, build_s = [], 0.0
+    for j in range(args.nlocal):
+        pth, bs = build_index(args, rank * args.nlocal + j, dev)
+        paths.append(pth)
+        build_s += bs
+    path = paths[0]
+    ixs = [pydsm.Index(pth, device=local) for pth in paths]
+    ix = ixs[0]
     plen = args.prefix_len if args.prefix_len >= 0 else (1 if world == 1 else 2)  # >= world prefixes so every rank owns some output
     prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
-    pmin = 1 if world == 1 else 2
+    pmin = 1 if world * args.nlocal == 1 else 2
 
     # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
     # one collective per frontier level, nothing else on the data path
@@ -138,7 +145,7 @@ def main():
         ex = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))), world, dev)
         allgather, exchange = ex.allgather, ex.params()
     stream = torch.cuda.current_stream().cuda_stream
-    miner = pydsm.Miner([ix], fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
+    miner = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
                         exchange=exchange, stream=stream, emit_owner_only=world > 1)
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
@@ -202,8 +209,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if ix.n < 0xFFFFFFF0 else "u64",
             "data": "synthetic",
-            "config": {"workload": "%d synthetic read set(s) of %d x %d bp (n=%d BWT symbols each), one FM-index per GPU, "
-                                   "fmin=%d Emax=%g pmin=%d, %d prefixes" % (world, args.reads, args.rlen, ix.n, args.fmin, args.emax, pmin, len(prefixes)),
+            "config": {"workload": "%d synthetic read set(s) of %d x %d bp (n=%d BWT symbols each), %d FM-index(es) per GPU, "
+                                   "fmin=%d Emax=%g pmin=%d, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin, len(prefixes)),
                        "parallelism": "sample-per-gpu x%d, one all-gather per frontier level" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
@@ -217,10 +224,11 @@ def main():
                        "index_hbm_bytes": ix.device_bytes()},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and args.nlocal == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(path, args, pmin)
         print(json.dumps(out), flush=True)
-    ix.close()
+    for x in ixs:
+        x.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

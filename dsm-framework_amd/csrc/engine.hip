@@ -217,15 +217,24 @@ struct Xchg {
     u32 d;        // total samples = world * nlocal
     u64 slots;    // 4F of the level that produced it
 };
+__device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
+    if (x.nlocal == 1) { r = g; l = 0; }          // one sample per rank (multi-GPU runs)
+    else if (x.d == x.nlocal) { r = 0; l = g; }   // single process
+    else { r = g / x.nlocal; l = g % x.nlocal; }
+}
 template <typename P>
 __device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 slot) {
-    const u8* rb = x.base + (u64)(g / x.nlocal) * x.bpr;
-    return reinterpret_cast<const P*>(rb)[(u64)(g % x.nlocal) * x.slots + slot];
+    u32 r, l;
+    x_split(x, g, r, l);
+    const u8* rb = x.base + (u64)r * x.bpr;
+    return reinterpret_cast<const P*>(rb)[(u64)l * x.slots + slot];
 }
 template <typename P>
 __device__ __forceinline__ u8 x_left(const Xchg& x, u32 g, u64 slot) {
-    const u8* rb = x.base + (u64)(g / x.nlocal) * x.bpr + (u64)x.nlocal * x.slots * sizeof(P);
-    return rb[(u64)(g % x.nlocal) * x.slots + slot];
+    u32 r, l;
+    x_split(x, g, r, l);
+    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.slots * sizeof(P);
+    return rb[(u64)l * x.slots + slot];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,23 +244,49 @@ constexpr int MAX_LOCAL = 32;  // local indexes per process
 constexpr int ADV_SLOTS = 8;
 constexpr int ADV_TILE = 256 * ADV_SLOTS;
 
-// alive in any sample?  number of samples, merged left char (metaserver.cpp:383-387)
+// For 8 consecutive slots: number of samples that hold the child and the merged left char (metaserver.cpp:383-387).
+// Every sample's 8 frequencies and 8 left-char codes are fetched with vector loads (the columns are slot-contiguous).
 template <typename P>
-__device__ __forceinline__ u32 slot_eval(const Xchg& x, u64 j, u8& ml) {
-    u32 nT = 0;
-    ml = 0xFF;
-    for (u32 g = 0; g < x.d; ++g) {
-        if (x_freq<P>(x, g, j) != 0) {
-            ++nT;
-            u8 l = x_left<P>(x, g, j);
-            ml = ml == 0xFF ? l : (ml == l ? ml : (u8)5);
+__device__ __forceinline__ void slots_eval8(const Xchg& x, u64 base, u32 nTs[ADV_SLOTS], u8 mls[ADV_SLOTS]) {
+#pragma unroll
+    for (int k = 0; k < ADV_SLOTS; ++k) { nTs[k] = 0; mls[k] = 0xFF; }
+    if (base >= x.slots) return;  // slots is a multiple of 4; a thread's 8 slots are two whole parents or one
+    const bool full = base + ADV_SLOTS <= x.slots;
+    const u32 world = x.d / x.nlocal;
+    for (u32 r = 0; r < world; ++r) {
+        const u8* rb = x.base + (u64)r * x.bpr;
+        const u8* lb = rb + (u64)x.nlocal * x.slots * sizeof(P);
+        for (u32 l = 0; l < x.nlocal; ++l) {
+            const P* f = reinterpret_cast<const P*>(rb) + (u64)l * x.slots + base;
+            const u8* lc = lb + (u64)l * x.slots + base;
+            P fv[ADV_SLOTS];
+            u8 lv[ADV_SLOTS];
+            if (full) {
+                typedef typename Vec4<P>::type V;
+                V a = reinterpret_cast<const V*>(f)[0], b = reinterpret_cast<const V*>(f)[1];
+                fv[0] = a.x; fv[1] = a.y; fv[2] = a.z; fv[3] = a.w; fv[4] = b.x; fv[5] = b.y; fv[6] = b.z; fv[7] = b.w;
+                const u32* lw = reinterpret_cast<const u32*>(lc);  // 4-byte aligned for every F
+                u64 w = (u64)lw[0] | ((u64)lw[1] << 32);
+#pragma unroll
+                for (int k = 0; k < ADV_SLOTS; ++k) lv[k] = (u8)(w >> (8 * k));
+            } else {
+#pragma unroll
+                for (int k = 0; k < ADV_SLOTS; ++k) { fv[k] = k < 4 ? f[k] : (P)0; lv[k] = k < 4 ? lc[k] : (u8)0; }
+            }
+#pragma unroll
+            for (int k = 0; k < ADV_SLOTS; ++k) {
+                if (fv[k] != 0) {
+                    ++nTs[k];
+                    mls[k] = mls[k] == 0xFF ? lv[k] : (mls[k] == lv[k] ? mls[k] : (u8)5);
+                }
+            }
         }
     }
-    return nT;
 }
 
+// sinfo[j] = nT | merged-left << 12, written by the reduce pass when d > 1 so that the down-sweep does not re-read d columns
 template <typename P>
-__global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __restrict__ sums) {
+__global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __restrict__ sums, u16* __restrict__ sinfo) {
     const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
     u32 s = 0;
     if (x.d == 1) {
@@ -260,8 +295,14 @@ __global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __rest
         for (int k = 0; k < ADV_SLOTS; ++k)
             if (base + k < x.slots) s += f[base + k] != 0;
     } else {
-        for (int k = 0; k < ADV_SLOTS; ++k)
-            if (base + k < x.slots) { u8 ml; s += slot_eval<P>(x, base + k, ml) != 0; }
+        u32 nTs[ADV_SLOTS];
+        u8 mls[ADV_SLOTS];
+        slots_eval8<P>(x, base, nTs, mls);
+#pragma unroll
+        for (int k = 0; k < ADV_SLOTS; ++k) {
+            s += nTs[k] != 0;
+            if (base + k < x.slots) sinfo[base + k] = (u16)(nTs[k] | ((u32)(mls[k] & 7) << 12));
+        }
     }
     u32 tot;
     block_exclusive_scan<u32>(s, &tot);
@@ -279,6 +320,7 @@ struct AdvanceOut {
     u32* rp[MAX_LOCAL];
     const u32* tpos[MAX_LOCAL];
     u32 nlocal, rank;
+    const u16* sinfo;  // per-slot nT / merged left char from the reduce pass (d > 1, more than one block)
     // stream mode (d == 1)
     void* keep_freq;
     u8* keep_left;
@@ -290,19 +332,28 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
     u32 nTs[ADV_SLOTS];
     u8 mls[ADV_SLOTS];
     u32 s = 0;
+    if (x.d == 1) {
 #pragma unroll
-    for (int k = 0; k < ADV_SLOTS; ++k) {
-        nTs[k] = 0; mls[k] = 0xFF;
-        if (base + k < x.slots) {
-            if (x.d == 1) {
+        for (int k = 0; k < ADV_SLOTS; ++k) {
+            nTs[k] = 0; mls[k] = 0xFF;
+            if (base + k < x.slots) {
                 nTs[k] = reinterpret_cast<const P*>(x.base)[base + k] != 0;
                 if (nTs[k]) mls[k] = x.base[x.slots * sizeof(P) + base + k];
-            } else {
-                nTs[k] = slot_eval<P>(x, base + k, mls[k]);
             }
         }
-        s += nTs[k] != 0;
+    } else if (o.sinfo) {  // evaluated by the reduce pass
+#pragma unroll
+        for (int k = 0; k < ADV_SLOTS; ++k) {
+            u32 w = base + k < x.slots ? (u32)o.sinfo[base + k] : 0u;
+            nTs[k] = w & 0xFFF; mls[k] = (u8)(w >> 12);
+        }
+    } else {
+        slots_eval8<P>(x, base, nTs, mls);
+#pragma unroll
+        for (int k = 0; k < ADV_SLOTS; ++k) mls[k] &= 7;
     }
+#pragma unroll
+    for (int k = 0; k < ADV_SLOTS; ++k) s += nTs[k] != 0;
     u32 tot;
     u32 ex = block_exclusive_scan<u32>(s, &tot);
     const u32 off = offsets ? offsets[blockIdx.x] : 0u;
@@ -352,24 +403,23 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
     if (u >= F) return;
     const u32 cnt = nT[u];
     const u64 ord = order[u];
-    u32 mask[16];
-    u32 alive = 0;
+    u64 mbyid = 0;  // 4 presence bits per reader id (ids < 16)
     for (u32 k = 0; k < cnt; ++k) {
         u32 r = (u32)((ord >> (4 * k)) & 15);
-        u32 m = 0;
+        u64 m = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) m |= (x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
-        mask[k] = m;  // indexed by position in the parent's order
-        alive |= m;
+        for (int c = 0; c < 4; ++c) m |= (u64)(x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
+        mbyid |= m << (4 * r);
     }
     u64 ins[4] = {0, 0, 0, 0};
     u32 icnt[4] = {0, 0, 0, 0};
     // round 1: every reader of the parent reads its first child
     for (u32 k = 0; k < cnt; ++k) {
-        u32 m = mask[k];
+        u32 r = (u32)((ord >> (4 * k)) & 15);
+        u32 m = (u32)((mbyid >> (4 * r)) & 15);
         if (m) {
             int f = __ffs(m) - 1;
-            ins[f] |= (u64)((ord >> (4 * k)) & 15) << (4 * icnt[f]);
+            ins[f] |= (u64)r << (4 * icnt[f]);
             ++icnt[f];
         }
     }
@@ -383,10 +433,7 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
         // next round: the readers of this child (in its iteration order) read their next child
         for (u32 k = 0; k < icnt[i]; ++k) {
             u32 r = (u32)((rev >> (4 * k)) & 15);
-            u32 m = 0;
-            for (u32 q = 0; q < cnt; ++q)
-                if (((ord >> (4 * q)) & 15) == r) m = mask[q];
-            m &= ~((2u << i) - 1);
+            u32 m = (u32)((mbyid >> (4 * r)) & 15) & ~((2u << i) - 1);
             if (m) {
                 int g = __ffs(m) - 1;
                 ins[g] |= (u64)r << (4 * icnt[g]);
@@ -898,6 +945,7 @@ class Engine {
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
     u32 *adv_sums = nullptr, *scan_tmp = nullptr;
+    u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8 *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
     u64* order[2] = {nullptr, nullptr};
@@ -972,17 +1020,17 @@ class Engine {
         u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4 * 4)   // rec x2, rp x2, tpos
                    + (u64)nlocal * 4 * (sizeof(P) + 1)                         // send
                    + 2ull * d * 4 * (sizeof(P) + 1)                            // recv x2
-                   + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0);
+                   + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
         u64 fc = budget / 3 / perF;
         if (fc > (1u << 28)) fc = 1u << 28;
         if (fc > fbound) fc = fbound;
         if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         Fcap = (u32)fc;
-        bpr_cap = (u64)nlocal * 4 * Fcap * (sizeof(P) + 1);
+        bpr_cap = ((u64)nlocal * 4 * Fcap * (sizeof(P) + 1) + 15) & ~15ull;
         if (p.exchange_send && p.exchange_recv && world > 1) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
             // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
-            u64 cap_slots = p.exchange_bytes / ((u64)nlocal * (sizeof(P) + 1));
+            u64 cap_slots = (p.exchange_bytes - 16) / ((u64)nlocal * (sizeof(P) + 1));
             if (cap_slots / 4 < Fcap) Fcap = (u32)(cap_slots / 4);
             bpr_cap = p.exchange_bytes;
             xsend = (u8*)p.exchange_send;
@@ -1013,6 +1061,7 @@ class Engine {
         }
         const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
         if (int rc = dalloc(adv_sums, nadv)) return rc;
+        if (d > 1) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
@@ -1162,7 +1211,7 @@ class Engine {
         while (true) {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
-            const u64 bpr = (u64)nlocal * slots * (sizeof(P) + 1);
+            const u64 bpr = ((u64)nlocal * slots * (sizeof(P) + 1) + 15) & ~15ull;  // ranks start 16-byte aligned
             const int nxt = cur ^ 1;
             u8* send = world > 1 ? xsend : xrecv[xcur];
             ExpandArgs ea;
@@ -1217,7 +1266,8 @@ class Engine {
             if (nb == 1) {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
             } else {
-                hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums);
+                ao.sinfo = d > 1 ? sinfo : nullptr;
+                hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums, sinfo);
                 exclusive_scan<u32, u32>(adv_sums, adv_sums, nb, scan_tmp, d_totals, st);
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
             }
@@ -1245,7 +1295,9 @@ class Engine {
                     child.left = lf;
                 }
                 ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
-                if (order_mode == 1)
+                // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
+                if (!(emit || capture)) {}
+                else if (order_mode == 1)
                     hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.firstchild, order[nxt]);
                 else if (order_mode == 2 && d <= 64)
                     hipLaunchKernelGGL((order_big_kernel<P, 64>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
