@@ -736,6 +736,29 @@ static unsigned host_threads() {
 
 static const double LN2 = 0x1.62e42fefa39efp-1;  // the reference's log(2), folded by its compiler (metaserver.cpp:379,389)
 
+// (f+1)*log(f+1)/log(2) and log(N)/log(2) are pure functions of small integers: tabulated once with exactly the
+// reference's expression (metaserver.cpp:379,389), so a lookup returns the very double the inline evaluation would.
+constexpr u32 TERM_TAB = 1u << 16, LOGN_TAB = 1u << 20;
+static const double* term_table() {
+    static std::vector<double> t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        t.resize(TERM_TAB);
+        for (u32 f = 0; f < TERM_TAB; ++f) t[f] = (double)((u64)f + 1) * log((double)((u64)f + 1)) / LN2;
+    });
+    return t.data();
+}
+static const double* logn_table() {
+    static std::vector<double> t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        t.resize(LOGN_TAB);
+        t[0] = 0;
+        for (u32 n = 1; n < LOGN_TAB; ++n) t[n] = log((double)n) / LN2;
+    });
+    return t.data();
+}
+
 // One emit job: the candidates of one prefix, already in pinned host memory.  Exact entropy
 // (metaserver.cpp:366-389), the emin/emax test (:413), order-preserving compaction, delivery.
 struct RawBuf {
@@ -767,12 +790,32 @@ struct PinBuf {
     }
     ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
+struct DevGrow {  // device buffer that only grows
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(DSM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    ~DevGrow() { if (p) (void)hipFree(p); }
+};
 struct EmitSet {
+    DevGrow dev[5];  // same five arrays on the device: they outlive the arena while the copy stream drains them
+    hipEvent_t ready = nullptr;  // recorded on the copy stream after the last device-to-host copy
+    int device = 0;
     PinBuf pin[5];   // path_off, pair_off, ids, freqs, paths (device order = post-order rank)
     RawBuf out[6];   // o_path, o_pair, ent, paths, ids, freqs (kept tuples only)
     RawBuf ent_all, keep;
     u32 nt = 0;
     bool busy = false;
+    ~EmitSet() { if (ready) (void)hipEventDestroy(ready); }
 };
 
 static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
@@ -791,6 +834,8 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
     const u32 per = (nt + nth - 1) / nth;
     std::vector<u64> cnt_t(nth + 1, 0), cnt_p(nth + 1, 0), cnt_q(nth + 1, 0);
     auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; };
+    const double* terms = term_table();
+    const double* logn = logn_table();
     auto pass1 = [&](unsigned t) {
         u32 lo, hi;
         range(t, lo, hi);
@@ -801,9 +846,9 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
             for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
                 u64 f = freqs[q];
                 sumN += f;
-                sumNlogN += (double)(f + 1) * log((double)(f + 1)) / LN2;
+                sumNlogN += f < TERM_TAB ? terms[f] : (double)(f + 1) * log((double)(f + 1)) / LN2;
             }
-            double e = log((double)sumN) / LN2 - sumNlogN / (double)sumN;
+            double e = (sumN < LOGN_TAB ? logn[sumN] : log((double)sumN) / LN2) - sumNlogN / (double)sumN;
             ent[r] = e;
             bool k = !(emax > 0 && (e < emin || e > emax));
             keep[r] = k;
@@ -885,7 +930,9 @@ struct Emitter {
             }
             u64 t = 0, pq = 0;
             double m = 0;
-            int rc = emit_job(set[k], d, emin, emax, sink, ctx, &t, &pq, &m);
+            (void)hipSetDevice(set[k].device);
+            int rc = set[k].ready && hipEventSynchronize(set[k].ready) != hipSuccess ? 1 : 0;  // copies of this set have landed
+            if (!rc) rc = emit_job(set[k], d, emin, emax, sink, ctx, &t, &pq, &m);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 tuples += t; pairs += pq; ms += m;
@@ -973,6 +1020,8 @@ class Engine {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (fill_done) (void)hipEventDestroy(fill_done);
     }
 
     template <class T> int dalloc(T*& p, size_t n) {
@@ -1449,11 +1498,20 @@ class Engine {
         LevelDev* d_lv;
         ARENA_GET(d_lv, LevelDev, nlev);
         DSM_HIP(hipMemcpyAsync(d_lv, lv.data(), nlev * sizeof(LevelDev), hipMemcpyHostToDevice, st));
-        u32 *plen, *npair, *path_off, *pair_off;
+        // The tuple arrays live in the emit set (not the arena): the copy stream drains them to pinned memory while the
+        // compute stream already expands the next prefix.
+        EmitSet& E = emitter.acquire();
+        E.device = device;
+        if (!E.ready) DSM_HIP(hipEventCreateWithFlags(&E.ready, hipEventDisableTiming));
+        if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (!fill_done) DSM_HIP(hipEventCreateWithFlags(&fill_done, hipEventDisableTiming));
+        u32 *plen, *npair;
         ARENA_GET(plen, u32, nt);
         ARENA_GET(npair, u32, nt);
-        ARENA_GET(path_off, u32, (size_t)nt + 1);
-        ARENA_GET(pair_off, u32, (size_t)nt + 1);
+        if (int rc = E.dev[0].ensure(((size_t)nt + 1) * 4)) return rc;
+        if (int rc = E.dev[1].ensure(((size_t)nt + 1) * 4)) return rc;
+        u32* path_off = (u32*)E.dev[0].p;
+        u32* pair_off = (u32*)E.dev[1].p;
         hipLaunchKernelGGL(tuple_size_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, plen, npair);
         u32* stmp;
         ARENA_GET(stmp, u32, scan_tmp_elems(nt) + 8);
@@ -1464,32 +1522,34 @@ class Engine {
         DSM_HIP(hipMemcpyAsync(h_totals, d_totals, 2 * sizeof(u32), hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
         const u64 path_bytes = h_totals[0], npairs = h_totals[1];
-        char* d_paths;
-        u32* d_ids;
-        u64* d_freqs;
-        ARENA_GET(d_paths, char, path_bytes);
-        ARENA_GET(d_ids, u32, npairs);
-        ARENA_GET(d_freqs, u64, npairs);
+        if (int rc = E.dev[2].ensure((size_t)npairs * 4)) return rc;
+        if (int rc = E.dev[3].ensure((size_t)npairs * 8)) return rc;
+        if (int rc = E.dev[4].ensure((size_t)path_bytes)) return rc;
+        u32* d_ids = (u32*)E.dev[2].p;
+        u64* d_freqs = (u64*)E.dev[3].p;
+        char* d_paths = (char*)E.dev[4].p;
         hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs);
         DSM_HIP(hipGetLastError());
-        // ---- to the host: pinned staging set, then the emitter thread takes over ------------------
-        EmitSet& E = emitter.acquire();
+        DSM_HIP(hipEventRecord(fill_done, st));
         if (int rc = E.pin[0].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.pin[1].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.pin[2].ensure((size_t)npairs * 4)) return rc;
         if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
         if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
-        DSM_HIP(hipMemcpyAsync(E.pin[0].p, path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(E.pin[1].p, pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(E.pin[2].p, d_ids, npairs * 4, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(E.pin[3].p, d_freqs, npairs * 8, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipMemcpyAsync(E.pin[4].p, d_paths, path_bytes, hipMemcpyDeviceToHost, st));
-        DSM_HIP(hipStreamSynchronize(st));
+        DSM_HIP(hipStreamWaitEvent(copy_stream, fill_done, 0));
+        DSM_HIP(hipMemcpyAsync(E.pin[0].p, path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+        DSM_HIP(hipMemcpyAsync(E.pin[1].p, pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+        DSM_HIP(hipMemcpyAsync(E.pin[2].p, d_ids, npairs * 4, hipMemcpyDeviceToHost, copy_stream));
+        DSM_HIP(hipMemcpyAsync(E.pin[3].p, d_freqs, npairs * 8, hipMemcpyDeviceToHost, copy_stream));
+        DSM_HIP(hipMemcpyAsync(E.pin[4].p, d_paths, path_bytes, hipMemcpyDeviceToHost, copy_stream));
+        DSM_HIP(hipEventRecord(E.ready, copy_stream));
         E.nt = nt;
         emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
         emitter.submit();
         return 0;
     }
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t fill_done = nullptr;
 
     // wait for the emitter and fold its counters into stats
     int finish_emits() {
