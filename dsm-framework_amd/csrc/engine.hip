@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     for (int q = 0; q < w; ++q) pos += wtot[q];
     if (i < a.F) {
         const size_t slot0 = (size_t)i * 4;
+        u32 lword = 0;  // the four left-char codes of this parent, one dword store
         if (present) {
+            tpos[i] = pos;  // children of one parent get consecutive handles: child c is at tpos + #present children before c
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (!((present >> c) & 1u)) continue;
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                     if (fits) { out[(size_t)(2 + kk) * a.cap + pos] = cmin; out[(size_t)(6 + kk) * a.cap + pos] = cmax; }
                 }
                 // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
-                cleft[slot0 + c] = matches ? (u8)(1 + lc) : (any ? (u8)5 : (u8)0);
-                tpos[slot0 + c] = pos;
+                lword |= (matches ? (1u + lc) : (any ? 5u : 0u)) << (8 * c);
                 ++pos;
             }
         }
+        reinterpret_cast<u32*>(cleft)[i] = lword;
         typename Vec4<P>::type v;
         v.x = cf[0]; v.y = cf[1]; v.z = cf[2]; v.w = cf[3];
         *reinterpret_cast<typename Vec4<P>::type*>(cfreq + slot0) = v;
@@ -377,9 +379,21 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             o.slot[v] = (u32)j;
             o.nT[v] = (u16)nTs[k];
             o.mleft[v] = mls[k];
-            for (u32 sl = 0; sl < o.nlocal; ++sl) {
-                const u32 g = o.rank * o.nlocal + sl;
-                o.rp[sl][v] = x_freq<P>(x, g, j) != 0 ? o.tpos[sl][j] : DEAD;
+            if (x.d == 1) {  // the only sample: its present children are exactly the alive slots of this parent
+                o.rp[0][v] = o.tpos[0][u] + (nc - 1);
+            } else {
+                for (u32 sl = 0; sl < o.nlocal; ++sl) {
+                    const u32 g = o.rank * o.nlocal + sl;
+                    u32 before = 0;
+                    bool here = false;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const bool p = x_freq<P>(x, g, j0 + cc) != 0;
+                        before += (cc < c) && p;
+                        here = here || (cc == c && p);
+                    }
+                    o.rp[sl][v] = here ? o.tpos[sl][u] + before : DEAD;
+                }
             }
             if (o.keep_left) {
                 reinterpret_cast<P*>(o.keep_freq)[v] = reinterpret_cast<const P*>(x.base)[j];
@@ -987,7 +1001,7 @@ class Engine {
     u32 Fcap = 0;
     std::vector<P*> rec[2];     // compact child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
-    std::vector<u32*> tpos;     // record handle per child slot of the level being expanded
+    std::vector<u32*> tpos;     // handle of the first child record of every node of the level being expanded
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
@@ -1066,7 +1080,7 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4 * 4)   // rec x2, rp x2, tpos
+        u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4)   // rec x2, rp x2, tpos
                    + (u64)nlocal * 4 * (sizeof(P) + 1)                         // send
                    + 2ull * d * 4 * (sizeof(P) + 1)                            // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
@@ -1105,7 +1119,7 @@ class Engine {
             if (int rc = dalloc(b, (size_t)REC_FIELDS * Fcap)) return rc;
             if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
             if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
-            if (int rc = dalloc(tp, (size_t)slots)) return rc;
+            if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
             rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp);
         }
         const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
