@@ -91,7 +91,8 @@ template <> struct Vec4<u64> { typedef ulonglong4 type; };
 template <typename P>
 __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
                                                      u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ cfreq,
-                                                     u8* __restrict__ cleft, ExpandArgs a, u64* __restrict__ counters) {
+                                                     u8* __restrict__ cleft, ExpandArgs a, u64* __restrict__ counters,
+                                                     u32* __restrict__ blockcnt) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u64 n_lf = 0, n_rank = 0;
     u32 lines = 0;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     if (threadIdx.x == 0) {
         u32 tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
         sbase = tot ? atomicAdd(alloc, tot) : 0u;
+        if (blockcnt) blockcnt[blockIdx.x] = tot;  // single sample: these are the alive slots of the block's 1024 slots
     }
     if (threadIdx.x < 4) {
         u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -309,6 +311,14 @@ __global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __rest
     u32 tot;
     block_exclusive_scan<u32>(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single sample: the expand kernel already counted the alive slots per 256 parents; an advance tile is two of those
+__global__ void pair_sum_kernel(const u32* __restrict__ cnt, u32 ncnt, u32* __restrict__ sums, u32 nb) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u32 a0 = 2 * b < ncnt ? cnt[2 * b] : 0u, a1 = 2 * b + 1 < ncnt ? cnt[2 * b + 1] : 0u;
+    sums[b] = a0 + a1;
 }
 
 struct AdvanceOut {
@@ -1005,7 +1015,7 @@ class Engine {
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
-    u32 *adv_sums = nullptr, *scan_tmp = nullptr;
+    u32 *adv_sums = nullptr, *scan_tmp = nullptr, *blockcnt = nullptr;
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8 *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
@@ -1124,6 +1134,7 @@ class Engine {
         }
         const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
         if (int rc = dalloc(adv_sums, nadv)) return rc;
+        if (int rc = dalloc(blockcnt, (size_t)Fcap / 256 + 8)) return rc;
         if (d > 1) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
@@ -1299,7 +1310,7 @@ class Engine {
                 P* cf = reinterpret_cast<P*>(send) + (size_t)s * slots;
                 u8* cl = send + (size_t)nlocal * slots * sizeof(P) + (size_t)s * slots;
                 hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
-                                   tpos[s], cf, cl, ea, d_counters);
+                                   tpos[s], cf, cl, ea, d_counters, d == 1 ? blockcnt : (u32*)nullptr);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
@@ -1330,7 +1341,10 @@ class Engine {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
             } else {
                 ao.sinfo = d > 1 ? sinfo : nullptr;
-                hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums, sinfo);
+                if (d == 1)
+                    hipLaunchKernelGGL(pair_sum_kernel, grid_for(nb), dim3(256), 0, st, blockcnt, (u32)((F + 255) / 256), adv_sums, nb);
+                else
+                    hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums, sinfo);
                 exclusive_scan<u32, u32>(adv_sums, adv_sums, nb, scan_tmp, d_totals, st);
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
             }
