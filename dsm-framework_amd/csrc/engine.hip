@@ -543,18 +543,19 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
         if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
     }
     cand[v] = out ? 1 : 0;
-    key[v] = out ? (1ull | ((u64)t << 32)) : 0ull;
+    if (key) key[v] = out ? (1ull | ((u64)t << 32)) : 0ull;  // d == 1: one pair per candidate, the flag scan is enough
 }
 
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
 template <typename P>
 __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u64* __restrict__ order,
                                   const u16* __restrict__ order16, const u8* __restrict__ cand, const u64* __restrict__ keyscan,
+                                  const u32* __restrict__ idx32,
                                   u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= a.F || !cand[v]) return;
-    const u32 k = (u32)(keyscan[v] & 0xFFFFFFFFu);
-    u32 o = (u32)(keyscan[v] >> 32);
+    const u32 k = keyscan ? (u32)(keyscan[v] & 0xFFFFFFFFu) : idx32[v];
+    u32 o = keyscan ? (u32)(keyscan[v] >> 32) : k;
     cand_node[k] = v;
     cand_poff[k] = o;
     const u64 j = slot_of[v];
@@ -1419,21 +1420,28 @@ class Engine {
                 fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
                 Xchg xp = xview(xcur ^ 1, prev_slots, prev_bpr);
                 ARENA_GET(me.cand_flag, u8, F);
+                const bool one = d == 1;
                 hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], mleft[cur], me.firstchild, samechild,
-                                   me.cand_flag, cand_key);
-                exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-                DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+                                   me.cand_flag, one ? (u64*)nullptr : cand_key);
+                u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
+                if (one) {
+                    exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
+                    DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
+                } else {
+                    exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
+                    DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+                }
                 DSM_HIP(hipStreamSynchronize(st));
                 u64 tot = 0;
                 memcpy(&tot, h_totals + 48, sizeof tot);
                 me.ncand = (u32)(tot & 0xFFFFFFFFu);
-                me.npairs = (u32)(tot >> 32);
+                me.npairs = one ? me.ncand : (u32)(tot >> 32);
                 if (me.ncand) {
                     ARENA_GET(me.cand_node, u32, me.ncand);
                     ARENA_GET(me.cand_poff, u32, me.ncand);
                     ARENA_GET(me.ids, u32, me.npairs);
                     ARENA_GET(me.freqs, u64, me.npairs);
-                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], order16[cur], me.cand_flag, cand_keyscan,
+                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], order16[cur], me.cand_flag, one ? (const u64*)nullptr : cand_keyscan, idx32,
                                        me.cand_node, me.cand_poff, me.ids, me.freqs);
                 }
                 stats.candidates += me.ncand;
