@@ -90,8 +90,8 @@ template <> struct Vec4<u64> { typedef ulonglong4 type; };
 // counters (sharded): [0]=reported [1]=lf_steps [2]=rank_ops [3]=block lines fetched
 template <typename P>
 __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                                     u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ cfreq,
-                                                     u8* __restrict__ cleft, ExpandArgs a, u64* __restrict__ counters,
+                                                     u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ valf,
+                                                     u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
                                                      u32* __restrict__ blockcnt) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u64 n_lf = 0, n_rank = 0;
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     const bool live = r != DEAD;
     P sp = 1, ep = 0, emin[4], emax[4];
     P Rsp[4], Rep[4], Rlo[4][4], Rhi[4][4];
-    P cf[4] = {0, 0, 0, 0};
     u32 present = 0;  // bit c: child c is emitted
+    u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
     if (live) {
         sp = rec[r];
         ep = rec[(size_t)a.cap + r];
@@ -113,11 +113,21 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         ++lines;
         if (rc.b1 != rc.bi) { load_blk(ix.blk, rc.b1, rc.r1); ++lines; } else rc.b1 = ~0ull;
         u32 ne = 0;
+        {
+            bool any = false, matches = false;
+            u32 lc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            emin[k] = rec[(size_t)(2 + k) * a.cap + r];
-            emax[k] = rec[(size_t)(6 + k) * a.cap + r];
-            ne += emin[k] <= emax[k];
+            for (int k = 0; k < 4; ++k) {
+                emin[k] = rec[(size_t)(2 + k) * a.cap + r];
+                emax[k] = rec[(size_t)(6 + k) * a.cap + r];
+                if (emin[k] <= emax[k]) {
+                    ++ne;
+                    any = true; lc = k;
+                    if (emin[k] == sp && emax[k] == ep) matches = true;
+                }
+            }
+            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
+            mycode = matches ? 1u + lc : (any ? 5u : 0u);
         }
         rank4<P>(ix, rc, (u64)sp, Rsp, lines);  // LF(c, sp-1)
         const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
@@ -139,10 +149,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                 if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
                 if (nonempty) {
                     if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
-                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
-                        cf[c] = nep - nsp + 1;
-                        present |= 1u << c;
-                    }
+                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) present |= 1u << c;  // EnumerateQuery.cpp:186
                 }
             }
         }
@@ -176,16 +183,12 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     u32 pos = sbase + (inc - k);
     for (int q = 0; q < w; ++q) pos += wtot[q];
     if (i < a.F) {
-        const size_t slot0 = (size_t)i * 4;
-        u32 lword = 0;  // the four left-char codes of this parent, one dword store
         if (present) {
             tpos[i] = pos;  // children of one parent get consecutive handles: child c is at tpos + #present children before c
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (!((present >> c) & 1u)) continue;
                 const P nsp = Rsp[c], nep = Rep[c] - 1;
-                bool any = false, matches = false;
-                u32 lc = 0;
                 const bool fits = pos < a.cap;  // overflow is detected by the host from *alloc
                 if (fits) { out[pos] = nsp; out[(size_t)a.cap + pos] = nep; }
 #pragma unroll
@@ -193,33 +196,27 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                     P cmin = 1, cmax = 0;
                     if (emin[kk] <= emax[kk]) {  // EnumerateQuery.cpp:44-55
                         P lo = Rlo[kk][c], hi = Rhi[kk][c] - 1;
-                        if (lo <= hi) {
-                            cmin = lo; cmax = hi;
-                            any = true; lc = kk;
-                            if (lo == nsp && hi == nep) matches = true;
-                        }
+                        if (lo <= hi) { cmin = lo; cmax = hi; }
                     }
                     if (fits) { out[(size_t)(2 + kk) * a.cap + pos] = cmin; out[(size_t)(6 + kk) * a.cap + pos] = cmax; }
                 }
-                // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
-                lword |= (matches ? (1u + lc) : (any ? 5u : 0u)) << (8 * c);
                 ++pos;
             }
         }
-        reinterpret_cast<u32*>(cleft)[i] = lword;
-        typename Vec4<P>::type v;
-        v.x = cf[0]; v.y = cf[1]; v.z = cf[2]; v.w = cf[3];
-        *reinterpret_cast<typename Vec4<P>::type*>(cfreq + slot0) = v;
+        // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
+        valf[i] = live ? (P)(ep - sp + 1) : (P)0;
+        pl[i] = (u8)(present | (mycode << 4));
     }
 }
 
-// view of one exchange buffer: rank-major, inside a rank [nlocal][slots] P then [nlocal][slots] u8
+// view of one exchange buffer: rank-major; inside a rank [nlocal][F] P (frequency of node v in the sample, 0 = absent)
+// then [nlocal][F] u8 (bits 0-3: surviving children of v in the sample, bits 4-6: left-char code of v)
 struct Xchg {
     const u8* base;
     u64 bpr;      // bytes per rank
     u32 nlocal;
     u32 d;        // total samples = world * nlocal
-    u64 slots;    // 4F of the level that produced it
+    u64 F;        // nodes of the level
 };
 __device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
     if (x.nlocal == 1) { r = g; l = 0; }          // one sample per rank (multi-GPU runs)
@@ -227,18 +224,18 @@ __device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
     else { r = g / x.nlocal; l = g % x.nlocal; }
 }
 template <typename P>
-__device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 slot) {
+__device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
     const u8* rb = x.base + (u64)r * x.bpr;
-    return reinterpret_cast<const P*>(rb)[(u64)l * x.slots + slot];
+    return reinterpret_cast<const P*>(rb)[(u64)l * x.F + v];
 }
 template <typename P>
-__device__ __forceinline__ u8 x_left(const Xchg& x, u32 g, u64 slot) {
+__device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
-    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.slots * sizeof(P);
-    return rb[(u64)l * x.slots + slot];
+    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * sizeof(P);
+    return rb[(u64)l * x.F + v];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -248,65 +245,36 @@ constexpr int MAX_LOCAL = 32;  // local indexes per process
 constexpr int ADV_SLOTS = 8;
 constexpr int ADV_TILE = 256 * ADV_SLOTS;
 
-// For 8 consecutive slots: number of samples that hold the child and the merged left char (metaserver.cpp:383-387).
-// Every sample's 8 frequencies and 8 left-char codes are fetched with vector loads (the columns are slot-contiguous).
+// For two consecutive parents (8 slots): how many samples keep each child (0 = the slot is not a union node).
 template <typename P>
-__device__ __forceinline__ void slots_eval8(const Xchg& x, u64 base, u32 nTs[ADV_SLOTS], u8 mls[ADV_SLOTS]) {
+__device__ __forceinline__ void slots_eval8(const Xchg& x, u64 u0, u32 nTs[ADV_SLOTS]) {
 #pragma unroll
-    for (int k = 0; k < ADV_SLOTS; ++k) { nTs[k] = 0; mls[k] = 0xFF; }
-    if (base >= x.slots) return;  // slots is a multiple of 4; a thread's 8 slots are two whole parents or one
-    const bool full = base + ADV_SLOTS <= x.slots;
+    for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] = 0;
+    if (u0 >= x.F) return;
+    const bool two = u0 + 1 < x.F;
     const u32 world = x.d / x.nlocal;
     for (u32 r = 0; r < world; ++r) {
-        const u8* rb = x.base + (u64)r * x.bpr;
-        const u8* lb = rb + (u64)x.nlocal * x.slots * sizeof(P);
+        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * sizeof(P);
         for (u32 l = 0; l < x.nlocal; ++l) {
-            const P* f = reinterpret_cast<const P*>(rb) + (u64)l * x.slots + base;
-            const u8* lc = lb + (u64)l * x.slots + base;
-            P fv[ADV_SLOTS];
-            u8 lv[ADV_SLOTS];
-            if (full) {
-                typedef typename Vec4<P>::type V;
-                V a = reinterpret_cast<const V*>(f)[0], b = reinterpret_cast<const V*>(f)[1];
-                fv[0] = a.x; fv[1] = a.y; fv[2] = a.z; fv[3] = a.w; fv[4] = b.x; fv[5] = b.y; fv[6] = b.z; fv[7] = b.w;
-                const u32* lw = reinterpret_cast<const u32*>(lc);  // 4-byte aligned for every F
-                u64 w = (u64)lw[0] | ((u64)lw[1] << 32);
+            const u8* q = pb + (u64)l * x.F + u0;
+            u32 m = (u32)(q[0] & 15) | (two ? (u32)(q[1] & 15) << 4 : 0u);
 #pragma unroll
-                for (int k = 0; k < ADV_SLOTS; ++k) lv[k] = (u8)(w >> (8 * k));
-            } else {
-#pragma unroll
-                for (int k = 0; k < ADV_SLOTS; ++k) { fv[k] = k < 4 ? f[k] : (P)0; lv[k] = k < 4 ? lc[k] : (u8)0; }
-            }
-#pragma unroll
-            for (int k = 0; k < ADV_SLOTS; ++k) {
-                if (fv[k] != 0) {
-                    ++nTs[k];
-                    mls[k] = mls[k] == 0xFF ? lv[k] : (mls[k] == lv[k] ? mls[k] : (u8)5);
-                }
-            }
+            for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] += (m >> k) & 1u;
         }
     }
 }
 
-// sinfo[j] = nT | merged-left << 12, written by the reduce pass when d > 1 so that the down-sweep does not re-read d columns
+// sinfo[j] = number of samples per slot, written by the reduce pass when d > 1 so that the down-sweep does not re-read d columns
 template <typename P>
 __global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __restrict__ sums, u16* __restrict__ sinfo) {
     const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
+    u32 nTs[ADV_SLOTS];
+    slots_eval8<P>(x, base >> 2, nTs);
     u32 s = 0;
-    if (x.d == 1) {
-        const P* f = reinterpret_cast<const P*>(x.base);
 #pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k)
-            if (base + k < x.slots) s += f[base + k] != 0;
-    } else {
-        u32 nTs[ADV_SLOTS];
-        u8 mls[ADV_SLOTS];
-        slots_eval8<P>(x, base, nTs, mls);
-#pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k) {
-            s += nTs[k] != 0;
-            if (base + k < x.slots) sinfo[base + k] = (u16)(nTs[k] | ((u32)(mls[k] & 7) << 12));
-        }
+    for (int k = 0; k < ADV_SLOTS; ++k) {
+        s += nTs[k] != 0;
+        if (base + k < x.F * 4) sinfo[base + k] = (u16)nTs[k];
     }
     u32 tot;
     block_exclusive_scan<u32>(s, &tot);
@@ -325,44 +293,26 @@ struct AdvanceOut {
     u32* slot;        // retained: 4*parent + sym of every new node
     u32* firstchild;  // retained, per parent (+ sentinel written by the host)
     u16* nT;          // per new node
-    u8* mleft;        // per new node
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
     // per local sample record handles
     u32* rp[MAX_LOCAL];
     const u32* tpos[MAX_LOCAL];
     u32 nlocal, rank;
-    const u16* sinfo;  // per-slot nT / merged left char from the reduce pass (d > 1, more than one block)
-    // stream mode (d == 1)
-    void* keep_freq;
-    u8* keep_left;
+    const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
 };
 
 template <typename P>
 __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __restrict__ offsets, AdvanceOut o, u32* __restrict__ total) {
     const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
+    const u64 slots = x.F * 4;
     u32 nTs[ADV_SLOTS];
-    u8 mls[ADV_SLOTS];
     u32 s = 0;
-    if (x.d == 1) {
+    if (o.sinfo) {  // evaluated by the reduce pass
 #pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k) {
-            nTs[k] = 0; mls[k] = 0xFF;
-            if (base + k < x.slots) {
-                nTs[k] = reinterpret_cast<const P*>(x.base)[base + k] != 0;
-                if (nTs[k]) mls[k] = x.base[x.slots * sizeof(P) + base + k];
-            }
-        }
-    } else if (o.sinfo) {  // evaluated by the reduce pass
-#pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k) {
-            u32 w = base + k < x.slots ? (u32)o.sinfo[base + k] : 0u;
-            nTs[k] = w & 0xFFF; mls[k] = (u8)(w >> 12);
-        }
+        for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] = base + k < slots ? (u32)o.sinfo[base + k] : 0u;
     } else {
-        slots_eval8<P>(x, base, nTs, mls);
-#pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k) mls[k] &= 7;
+        slots_eval8<P>(x, base >> 2, nTs);
     }
 #pragma unroll
     for (int k = 0; k < ADV_SLOTS; ++k) s += nTs[k] != 0;
@@ -374,40 +324,31 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const u64 j0 = base + 4 * half;
-        if (j0 >= x.slots) break;
+        if (j0 >= slots) break;
         const u32 u = (u32)(j0 >> 2);
         o.firstchild[u] = ex;
         u32 nc = 0, lastT = 0;
+        const u32 v0 = ex;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = 4 * half + c;
             if (!nTs[k]) continue;
-            const u64 j = j0 + c;
             const u32 v = ex++;
             ++nc;
             lastT = nTs[k];
-            o.slot[v] = (u32)j;
+            o.slot[v] = (u32)(j0 + c);
             o.nT[v] = (u16)nTs[k];
-            o.mleft[v] = mls[k];
-            if (x.d == 1) {  // the only sample: its present children are exactly the alive slots of this parent
-                o.rp[0][v] = o.tpos[0][u] + (nc - 1);
-            } else {
-                for (u32 sl = 0; sl < o.nlocal; ++sl) {
-                    const u32 g = o.rank * o.nlocal + sl;
-                    u32 before = 0;
-                    bool here = false;
+        }
+        if (nc) {
+            for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
+                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
+                u32 h = m ? o.tpos[sl][u] : 0u;
+                u32 v = v0;
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const bool p = x_freq<P>(x, g, j0 + cc) != 0;
-                        before += (cc < c) && p;
-                        here = here || (cc == c && p);
-                    }
-                    o.rp[sl][v] = here ? o.tpos[sl][u] + before : DEAD;
+                for (int c = 0; c < 4; ++c) {
+                    if (!nTs[4 * half + c]) continue;
+                    o.rp[sl][v++] = ((m >> c) & 1u) ? h++ : DEAD;
                 }
-            }
-            if (o.keep_left) {
-                reinterpret_cast<P*>(o.keep_freq)[v] = reinterpret_cast<const P*>(x.base)[j];
-                o.keep_left[v] = mls[k];
             }
         }
         o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
@@ -430,9 +371,7 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
     u64 mbyid = 0;  // 4 presence bits per reader id (ids < 16)
     for (u32 k = 0; k < cnt; ++k) {
         u32 r = (u32)((ord >> (4 * k)) & 15);
-        u64 m = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) m |= (u64)(x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
+        u64 m = x_pl<P>(x, r, u) & 15u;  // which children this reader continues into
         mbyid |= m << (4 * r);
     }
     u64 ins[4] = {0, 0, 0, 0};
@@ -482,9 +421,7 @@ __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, cons
     u32 icnt[4] = {0, 0, 0, 0};
     for (u32 k = 0; k < cnt; ++k) {  // round 1: every reader of the parent reads its first child
         const u32 r = ord[k];
-        u32 m = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) m |= (x_freq<P>(x, r, (u64)u * 4 + c) != 0 ? 1u : 0u) << c;
+        u32 m = x_pl<P>(x, r, u) & 15u;
         mask[r] = (u8)m;
         if (m) { int f = __ffs(m) - 1; ins[f][icnt[f]++] = (u16)r; }
     }
@@ -516,7 +453,7 @@ struct FilterArgs {
 // within 1e-9 of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
 // key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
 template <typename P>
-__global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u8* __restrict__ mleft,
+__global__ void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT,
                               const u32* __restrict__ firstchild, const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= a.F) return;
@@ -526,21 +463,24 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
     if (a.pmax != 0 && t > a.pmax) out = false;
     if (t < a.pmin) out = false;
     if (firstchild[v + 1] - firstchild[v] == 1 && samechild[v]) out = false;
-    const u8 l = mleft[v];
-    if (l >= 1 && l <= 4) out = false;
-    if (out && a.emax > 0) {
+    if (out) {  // merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
         u64 sumN = a.d;
         double s = 0;
-        const u64 j = slot_of[v];
+        u32 l = 0xFF;
         for (u32 g = 0; g < a.d; ++g) {
-            u64 f = (u64)x_freq<P>(x, g, j);
+            u64 f = (u64)x_freq<P>(x, g, v);
             if (f) {
+                u32 lg = x_pl<P>(x, g, v) >> 4;
+                l = l == 0xFF ? lg : (l == lg ? l : 5u);
                 sumN += f;
-                s += (double)(f + 1) * log2((double)(f + 1));
+                if (a.emax > 0) s += (double)(f + 1) * log2((double)(f + 1));
             }
         }
-        double e = log2((double)sumN) - s / (double)sumN;
-        if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
+        if (l >= 1 && l <= 4) out = false;
+        if (out && a.emax > 0) {
+            double e = log2((double)sumN) - s / (double)sumN;
+            if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
+        }
     }
     cand[v] = out ? 1 : 0;
     if (key) key[v] = out ? (1ull | ((u64)t << 32)) : 0ull;  // d == 1: one pair per candidate, the flag scan is enough
@@ -548,7 +488,7 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot
 
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
 template <typename P>
-__global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ slot_of, const u16* __restrict__ nT, const u64* __restrict__ order,
+__global__ void cand_store_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order,
                                   const u16* __restrict__ order16, const u8* __restrict__ cand, const u64* __restrict__ keyscan,
                                   const u32* __restrict__ idx32,
                                   u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
@@ -558,7 +498,7 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ 
     u32 o = keyscan ? (u32)(keyscan[v] >> 32) : k;
     cand_node[k] = v;
     cand_poff[k] = o;
-    const u64 j = slot_of[v];
+    const u64 j = v;
     if (a.exact_order == 1) {
         const u64 ord = order[v];
         const u32 cnt = nT[v];
@@ -579,6 +519,15 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u32* __restrict__ 
             if (f) { ids[o] = g; freqs[o] = f; ++o; }
         }
     }
+}
+
+// stream mode (one sample): frequency and left char of every node of the level are retained for the wire stream
+template <typename P>
+__global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict__ left) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    freq[v] = x_freq<P>(x, 0, v);
+    left[v] = (u8)(x_pl<P>(x, 0, v) >> 4);
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
@@ -1019,14 +968,12 @@ class Engine {
     u32 *adv_sums = nullptr, *scan_tmp = nullptr, *blockcnt = nullptr;
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
-    u8 *mleft[2] = {nullptr, nullptr}, *samechild = nullptr;
+    u8* samechild = nullptr;
     u64* order[2] = {nullptr, nullptr};
     u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_key = nullptr, *cand_keyscan = nullptr, *scan_tmp64 = nullptr;
     u64* d_counters = nullptr;
     u32* d_alloc = nullptr;   // [nlocal] compact-record allocation counters
-    P* stage_freq = nullptr;  // stream mode: freq / left char of the new level before they move to the arena
-    u8* stage_left = nullptr;
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, then u64 totals
@@ -1092,20 +1039,20 @@ class Engine {
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
         u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4)   // rec x2, rp x2, tpos
-                   + (u64)nlocal * 4 * (sizeof(P) + 1)                         // send
-                   + 2ull * d * 4 * (sizeof(P) + 1)                            // recv x2
+                   + (u64)nlocal * (sizeof(P) + 1)                             // send
+                   + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
         u64 fc = budget / 3 / perF;
         if (fc > (1u << 28)) fc = 1u << 28;
         if (fc > fbound) fc = fbound;
         if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         Fcap = (u32)fc;
-        bpr_cap = ((u64)nlocal * 4 * Fcap * (sizeof(P) + 1) + 15) & ~15ull;
+        bpr_cap = ((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull;
         if (p.exchange_send && p.exchange_recv && world > 1) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
             // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
             u64 cap_slots = (p.exchange_bytes - 16) / ((u64)nlocal * (sizeof(P) + 1));
-            if (cap_slots / 4 < Fcap) Fcap = (u32)(cap_slots / 4);
+            if (cap_slots < Fcap) Fcap = (u32)cap_slots;
             bpr_cap = p.exchange_bytes;
             xsend = (u8*)p.exchange_send;
             xrecv[0] = (u8*)p.exchange_recv;
@@ -1140,17 +1087,12 @@ class Engine {
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
-            if (int rc = dalloc(mleft[k], Fcap)) return rc;
             if (int rc = dalloc(order[k], Fcap)) return rc;
         }
         if (d > 13)
             for (int k = 0; k < 2; ++k)
                 if (int rc = dalloc(order16[k], (size_t)Fcap * d)) return rc;
         if (int rc = dalloc(samechild, Fcap)) return rc;
-        if (stream_mode) {
-            if (int rc = dalloc(stage_freq, Fcap)) return rc;
-            if (int rc = dalloc(stage_left, Fcap)) return rc;
-        }
         if (int rc = dalloc(cand_key, Fcap)) return rc;
         if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
@@ -1193,13 +1135,13 @@ class Engine {
         return 0;
     }
 
-    Xchg xview(int which, u64 slots, u64 bpr) const {
+    Xchg xview(int which, u64 F_, u64 bpr) const {
         Xchg x;
         x.base = xrecv[which];
         x.bpr = bpr;
         x.nlocal = (u32)nlocal;
         x.d = d;
-        x.slots = slots;
+        x.F = F_;
         return x;
     }
 
@@ -1278,15 +1220,14 @@ class Engine {
         const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);  // (declared before the level loop: used by seed/capture)
         stats.pair_order_exact = 1;
 
-        int cur = 0;      // ping-pong index of the current level (rec, rp, nT, mleft, order)
+        int cur = 0;      // ping-pong index of the current level (rec, rp, nT, order)
         int xcur = 0;     // exchange buffer that will receive the current level's children
         u32 F = 1;
         u32 depth = 0;
-        u64 prev_slots = 0, prev_bpr = 0;  // exchange view that holds the freqs of the current level's nodes
         while (true) {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
-            const u64 bpr = ((u64)nlocal * slots * (sizeof(P) + 1) + 15) & ~15ull;  // ranks start 16-byte aligned
+            const u64 bpr = ((u64)nlocal * F * (sizeof(P) + 1) + 15) & ~15ull;  // ranks start 16-byte aligned
             const int nxt = cur ^ 1;
             u8* send = world > 1 ? xsend : xrecv[xcur];
             ExpandArgs ea;
@@ -1308,8 +1249,8 @@ class Engine {
                 const IndexMeta& m = idx[s]->meta;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
-                P* cf = reinterpret_cast<P*>(send) + (size_t)s * slots;
-                u8* cl = send + (size_t)nlocal * slots * sizeof(P) + (size_t)s * slots;
+                P* cf = reinterpret_cast<P*>(send) + (size_t)s * F;                        // this sample's frequency column
+                u8* cl = send + (size_t)nlocal * F * sizeof(P) + (size_t)s * F;           // children nibble | left char << 4
                 hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
                                    tpos[s], cf, cl, ea, d_counters, d == 1 ? blockcnt : (u32*)nullptr);
                 ++stats.expand_launches;
@@ -1321,22 +1262,27 @@ class Engine {
                 int rc = prm.allgather(prm.allgather_ctx, xsend, xrecv[xcur], (size_t)bpr, (void*)st);
                 if (rc) return fail(DSM_E_SINK, "allgather callback failed");
             }
-            Xchg x = xview(xcur, slots, bpr);
+            Xchg x = xview(xcur, F, bpr);
             // ---- union frontier of the next level -------------------------------------------------
             LevelHost& me = L[depth];
             LevelHost child;
             // the arena hands out memory past `off`; the new level's arrays are claimed after Fn is known, so
             // the down-sweep writes into a provisional window that is then committed
-            const size_t mark = arena.off;
-            u32* new_slot = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
-            if (!new_slot) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
-            void* keep_freq = stream_mode ? (void*)stage_freq : nullptr;
-            u8* keep_left = stream_mode ? stage_left : nullptr;
+            if (stream_mode && depth >= 1) {  // this level's own frequencies / left chars go to the wire stream
+                P* fq;
+                ARENA_GET(fq, P, F);
+                ARENA_GET(me.left, u8, F);
+                me.freq = fq;
+                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, fq, me.left);
+            }
+            const size_t mark2 = arena.off;
+            u32* new_slot2 = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
+            if (!new_slot2) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
             const u32 nb = (u32)((slots + ADV_TILE - 1) / ADV_TILE);
             AdvanceOut ao;
             memset(&ao, 0, sizeof ao);
-            ao.slot = new_slot; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.mleft = mleft[nxt]; ao.samechild = samechild;
-            ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank; ao.keep_freq = keep_freq; ao.keep_left = keep_left;
+            ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
+            ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             for (int s = 0; s < nlocal; ++s) { ao.rp[s] = rp[nxt][s]; ao.tpos[s] = tpos[s]; }
             if (nb == 1) {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
@@ -1358,20 +1304,10 @@ class Engine {
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             DSM_HIP(hipMemcpyAsync(me.firstchild + F, &h_totals[0], sizeof(u32), hipMemcpyHostToDevice, st));  // sentinel
             // commit the provisional window at its real size
-            arena.off = mark;
+            arena.off = mark2;
             child.n = Fn;
             if (Fn) {
-                child.slot = arena.get<u32>(Fn);  // same address as new_slot
-                if (stream_mode) {  // freq / left char of every node are retained for the wire stream
-                    P* fq;
-                    u8* lf;
-                    ARENA_GET(fq, P, Fn);
-                    ARENA_GET(lf, u8, Fn);
-                    DSM_HIP(hipMemcpyAsync(fq, stage_freq, (size_t)Fn * sizeof(P), hipMemcpyDeviceToDevice, st));
-                    DSM_HIP(hipMemcpyAsync(lf, stage_left, (size_t)Fn, hipMemcpyDeviceToDevice, st));
-                    child.freq = fq;
-                    child.left = lf;
-                }
+                child.slot = arena.get<u32>(Fn);  // same address as new_slot2
                 ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
                 // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
                 if (!(emit || capture)) {}
@@ -1418,10 +1354,10 @@ class Engine {
                 FilterArgs fa;
                 fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
                 fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
-                Xchg xp = xview(xcur ^ 1, prev_slots, prev_bpr);
+                const Xchg& xp = x;  // the columns of THIS level's nodes arrived with this level's exchange
                 ARENA_GET(me.cand_flag, u8, F);
                 const bool one = d == 1;
-                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], mleft[cur], me.firstchild, samechild,
+                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
                                    me.cand_flag, one ? (u64*)nullptr : cand_key);
                 u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
                 if (one) {
@@ -1441,7 +1377,7 @@ class Engine {
                     ARENA_GET(me.cand_poff, u32, me.ncand);
                     ARENA_GET(me.ids, u32, me.npairs);
                     ARENA_GET(me.freqs, u64, me.npairs);
-                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, me.slot, nT[cur], order[cur], order16[cur], me.cand_flag, one ? (const u64*)nullptr : cand_keyscan, idx32,
+                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag, one ? (const u64*)nullptr : cand_keyscan, idx32,
                                        me.cand_node, me.cand_poff, me.ids, me.freqs);
                 }
                 stats.candidates += me.ncand;
@@ -1452,7 +1388,6 @@ class Engine {
             ++stats.levels;
             if (!Fn) break;
             L.push_back(child);
-            prev_slots = slots; prev_bpr = bpr;
             cur = nxt;
             xcur ^= 1;
             F = Fn;
