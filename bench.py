@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="independent prefix lanes (own stream, own communicator) that overlap one lane's "
+                    "all-gather with the other's kernels; default 1")
     ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
     ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
     return ap.parse_args()
@@ -103,6 +105,9 @@ def cpu_baseline(path, args, pmin):
 
 def main():
     args = parse()
+    if os.environ.get("DSM_BENCH_WATCHDOG"):  # rehearsal aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DSM_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,33 +142,83 @@ def main():
     pmin = 1 if world * args.nlocal == 1 else 2
 
     # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
-    # one collective per frontier level, nothing else on the data path
-    allgather = None
-    exchange = None
-    if world > 1:
-        from pydsm.dist import Exchange
-        ex = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))), world, dev)
-        allgather, exchange = ex.allgather, ex.params()
-    stream = torch.cuda.current_stream().cuda_stream
-    miner = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
-                        exchange=exchange, stream=stream, emit_owner_only=world > 1)
+    # one collective per frontier level, nothing else on the data path.  A lane = one miner with its own HIP stream and
+    # (multi-rank) its own communicator; lanes take the prefixes round-robin and run concurrently, so one lane's
+    # collective overlaps the other lane's kernels.
+    # Default is one lane: two lanes (two communicators driven from two threads, collectives interleaved deterministically by
+    # pydsm.dist.TurnGate) hide the all-gather behind the other lane's kernels and have been rehearsed with gloo on one card,
+    # but not yet with RCCL on a multi-GPU node; opt in with --lanes 2 or DSM_BENCH_LANES=2.
+    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1"))
+    nlanes = max(1, min(nlanes, len(prefixes)))
+    lanes = []
+    gate = None
+    if world > 1 and nlanes > 1:
+        from pydsm.dist import TurnGate
+        gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
+    for j in range(nlanes):
+        lane = {"prefixes": prefixes[j::nlanes], "stream": torch.cuda.Stream(device=dev) if nlanes > 1 else torch.cuda.current_stream()}
+        allgather = exchange = None
+        if world > 1:
+            from pydsm.dist import Exchange
+            group = dist.new_group(ranks=list(range(world))) if nlanes > 1 else None
+            lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
+            allgather, exchange = lane["ex"].allgather, lane["ex"].params()
+        arena = 0
+        if nlanes > 1:  # split what is left between the lanes still to be created (and the ranks sharing this card)
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            sharing = (world + ndev - 1) // max(1, ndev)
+            want = (256 << 20) + 900 * sum(x.n for x in ixs) * world
+            arena = int(min(want, free_b * 0.8 / (nlanes - j) / sharing))
+        lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
+                                    exchange=exchange, stream=lane["stream"].cuda_stream, emit_owner_only=world > 1, arena_bytes=arena)
+        lanes.append(lane)
+    if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
+        for ln in lanes:
+            ln["ex"].gate = gate
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
            "device_ms": 0.0, "host_ms": 0.0, "cand": 0}
+    import threading
+    tot_lock = threading.Lock()
+
+    def lane_step(lane, record, errs):
+        try:
+            if gate is not None:
+                gate.begin(lanes.index(lane))
+            with torch.cuda.stream(lane["stream"]):
+                st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
+            if record:
+                with tot_lock:
+                    tot["reported"] += st.reported
+                    tot["rank_ops"] += st.rank_ops
+                    tot["lf_steps"] += st.lf_steps
+                    tot["expand_ms"] += st.expand_ms
+                    tot["launches"] += st.expand_launches
+                    tot["tuples"] += st.tuples
+                    tot["union"] += st.union_nodes
+                    tot["device_ms"] += st.device_ms
+                    tot["host_ms"] += st.host_ms
+                    tot["cand"] += st.candidates
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+        finally:
+            if gate is not None:
+                gate.retire(lanes.index(lane))
 
     def step(record):
-        for st in (miner.mine_many(prefixes, text=False)[1],):
-            if record:
-                tot["reported"] += st.reported
-                tot["rank_ops"] += st.rank_ops
-                tot["lf_steps"] += st.lf_steps
-                tot["expand_ms"] += st.expand_ms
-                tot["launches"] += st.expand_launches
-                tot["tuples"] += st.tuples
-                tot["union"] += st.union_nodes
-                tot["device_ms"] += st.device_ms
-                tot["host_ms"] += st.host_ms
-                tot["cand"] += st.candidates
+        errs = []
+        if gate is not None:
+            gate.reset()
+        if len(lanes) == 1:
+            lane_step(lanes[0], record, errs)
+        else:
+            ths = [threading.Thread(target=lane_step, args=(ln, record, errs)) for ln in lanes]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        if errs:
+            raise errs[0]
 
     def barrier():
         if world > 1:
@@ -172,7 +227,7 @@ def main():
 
     if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1:
         import atexit
-        atexit.register(lambda: print("TRACE rank %d: %s" % (rank, ex.trace[:60]), file=sys.stderr, flush=True))
+        atexit.register(lambda: print("TRACE rank %d: %s" % (rank, lanes[0]["ex"].trace[:60]), file=sys.stderr, flush=True))
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -191,7 +246,8 @@ def main():
         reported_all = float(tsum[1])
     else:
         reported_all = float(tot["reported"])
-    miner.close()
+    for ln in lanes:
+        ln["miner"].close()
 
     if rank == 0:
         ach = tot["rank_ops"] * ALG_BYTES_PER_RANK / (tot["expand_ms"] * 1e-3) / 1e9 if tot["expand_ms"] > 0 else 0.0
@@ -211,7 +267,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d synthetic read set(s) of %d x %d bp (n=%d BWT symbols each), %d FM-index(es) per GPU, "
                                    "fmin=%d Emax=%g pmin=%d, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin, len(prefixes)),
-                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level" % world},
+                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),

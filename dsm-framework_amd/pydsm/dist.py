@@ -6,11 +6,68 @@ import torch
 import torch.distributed as dist
 
 
+class TurnGate:
+    """Deterministic interleaving of the collectives of several lanes (threads) of one process.
+
+    Every rank runs the same lanes over the same prefixes, so each lane issues the same number of collectives on every
+    rank; strict round-robin between the lanes that are still active therefore enqueues collectives of different
+    communicators in the same order on all ranks (required for NCCL/RCCL communicators used concurrently)."""
+
+    def __init__(self, nlanes):
+        import threading
+        self.cv = threading.Condition()
+        self.active = [True] * nlanes
+        self.turn = 0
+
+    def _advance(self):
+        n = len(self.active)
+        for k in range(1, n + 1):
+            j = (self.turn + k) % n
+            if self.active[j]:
+                self.turn = j
+                return
+
+    def acquire(self, lane):
+        with self.cv:
+            self.cv.wait_for(lambda: self.turn == lane)
+
+    def release(self, lane):
+        with self.cv:
+            self._advance()
+            self.cv.notify_all()
+
+    def begin(self, lane):
+        with self.cv:
+            self.active[lane] = True
+
+    def retire(self, lane):
+        with self.cv:
+            self.active[lane] = False
+            if self.turn == lane:
+                self._advance()
+            self.cv.notify_all()
+
+    def reset(self):
+        with self.cv:
+            self.active = [True] * len(self.active)
+            self.turn = 0
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Exchange:
     """Owns the send / recv buffers handed to dsm_params.exchange_* and implements dsm_allgather_fn."""
 
-    def __init__(self, nbytes, world_size, device, group=None):
-        self.nbytes = int(nbytes)
+    def __init__(self, nbytes, world_size, device, group=None, stream=None, gate=None, lane=0):
+        self.stream = stream  # torch.cuda.Stream the library's kernels run on (None = current stream)
+        self.gate, self.lane = gate, lane
+        self.nbytes = int(nbytes) & ~15
         self.world = int(world_size)
         self.group = group
         self.device = torch.device(device)
@@ -39,17 +96,34 @@ class Exchange:
         if nbytes > self.nbytes:
             raise ValueError("level larger than the exchange buffers")
         off = self.half(recv_ptr)
+        if self.gate is not None:
+            self.gate.acquire(self.lane)
+            try:
+                self._allgather(nbytes, off)
+            finally:
+                self.gate.release(self.lane)
+        else:
+            self._allgather(nbytes, off)
+        self.calls += 1
+        self.bytes_moved += nbytes * self.world
+
+    def _allgather(self, nbytes, off):
         if self.trace is not None:
             self.trace.append(int(nbytes))
         out = self.recv[off: off + nbytes * self.world]
         src = self.send[:nbytes]
-        if self.backend == "nccl" or self.device.type == "cpu":
+        if self.device.type == "cpu":
             dist.all_gather_into_tensor(out, src, group=self.group)
+        elif self.backend == "nccl":
+            # the collective is ordered after the library's kernels on its stream, and later kernels after the collective
+            with torch.cuda.stream(self.stream) if self.stream is not None else _null():
+                dist.all_gather_into_tensor(out, src, group=self.group)
         else:  # gloo with device buffers: stage through the host
-            torch.cuda.current_stream(self.device).synchronize()
-            h_out = torch.empty(nbytes * self.world, dtype=torch.uint8)
-            dist.all_gather_into_tensor(h_out, src.cpu(), group=self.group)
-            out.copy_(h_out)
-            torch.cuda.current_stream(self.device).synchronize()
-        self.calls += 1
-        self.bytes_moved += nbytes * self.world
+            st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(st):
+                st.synchronize()
+                h_src = src.cpu()
+                h_out = torch.empty(nbytes * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(h_out, h_src, group=self.group)
+                out.copy_(h_out)
+                st.synchronize()
