@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pmin", type=int, default=-1, help="metaserver -P; default 1 for a single sample, else 2")
+    ap.add_argument("--pmax", type=int, default=0, help="metaserver --pmax (BASELINE configs[3]: 8, configs[4]: 1)")
+    ap.add_argument("--wide", action="store_true", help="force 64-bit positions (the code path of n > 2^32, BASELINE configs[3])")
+    ap.add_argument("--stream-mode", action="store_true", help="time the wire-stream path (dsm_enumerate, the TCP drop-in client) instead of mining")
     ap.add_argument("--lanes", type=int, default=0, help="independent prefix lanes (own stream, own communicator) that overlap one lane's "
                     "all-gather with the other's kernels; default 1")
     ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
@@ -139,7 +143,7 @@ def main():
     ix = ixs[0]
     plen = args.prefix_len if args.prefix_len >= 0 else (1 if world <= 4 else 2)  # >= world prefixes so every rank owns some output
     prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
-    pmin = 1 if world * args.nlocal == 1 else 2
+    pmin = args.pmin if args.pmin > 0 else (1 if world * args.nlocal == 1 else 2)
 
     # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
     # one collective per frontier level, nothing else on the data path.  A lane = one miner with its own HIP stream and
@@ -169,8 +173,10 @@ def main():
             sharing = (world + ndev - 1) // max(1, ndev)
             want = (256 << 20) + 900 * sum(x.n for x in ixs) * world
             arena = int(min(want, free_b * 0.8 / (nlanes - j) / sharing))
-        lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, emax=args.emax, world_size=world, rank=rank, allgather=allgather,
-                                    exchange=exchange, stream=lane["stream"].cuda_stream, emit_owner_only=world > 1, arena_bytes=arena)
+        lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
+                                    allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
+                                    emit_owner_only=world > 1, arena_bytes=arena, wide=1 if args.wide else 0,
+                                    stream_mode=args.stream_mode)
         lanes.append(lane)
     if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
         for ln in lanes:
@@ -186,7 +192,15 @@ def main():
             if gate is not None:
                 gate.begin(lanes.index(lane))
             with torch.cuda.stream(lane["stream"]):
-                st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
+                if args.stream_mode:
+                    st = pydsm.Stats()
+                    for pfx in lane["prefixes"]:
+                        nb, s1 = lane["miner"].enumerate(pfx, discard=True)
+                        tot["wire_bytes"] = tot.get("wire_bytes", 0) + (nb if record else 0)
+                        for k, _ in pydsm.Stats._fields_:
+                            setattr(st, k, getattr(st, k) + getattr(s1, k))
+                else:
+                    st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
             if record:
                 with tot_lock:
                     tot["reported"] += st.reported
@@ -263,10 +277,12 @@ def main():
         out = {
             "metric": "enumerated substrings/sec (Emax=2.0)", "value": reported_all / dt, "unit": "substrings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if ix.n < 0xFFFFFFF0 else "u64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if (args.wide or ix.n >= 0xFFFFFFF0) else "u32",
             "data": "synthetic",
             "config": {"workload": "%d synthetic read set(s) of %d x %d bp (n=%d BWT symbols each), %d FM-index(es) per GPU, "
-                                   "fmin=%d Emax=%g pmin=%d, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin, len(prefixes)),
+                                   "fmin=%d Emax=%g pmin=%d pmax=%d%s%s, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin,
+                                                                              args.pmax, ", 64-bit positions" if args.wide else "",
+                                                                              ", wire-stream mode" if args.stream_mode else "", len(prefixes)),
                        "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
@@ -277,7 +293,7 @@ def main():
                        "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
                        "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
                        "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,
-                       "index_hbm_bytes": ix.device_bytes()},
+                       "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps)},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
         if world == 1 and args.nlocal == 1 and not args.no_cpu:

@@ -1574,21 +1574,29 @@ class Engine {
             hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].slot, (const P*)L[l].freq, L[l].left, L[l].pre,
                                L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
         DSM_HIP(hipGetLastError());
-        // deliver in pieces through a pinned staging buffer
-        const size_t PIECE = 32u << 20;
-        if (int rc = stream_pin.ensure(PIECE)) return rc;
-        u8* h_piece = (u8*)stream_pin.p;
+        // deliver in pieces through two pinned staging buffers: piece k+1 is copied while the sink consumes piece k
+        const size_t PIECE = 64u << 20;
+        if (int rc = stream_pin[0].ensure(PIECE)) return rc;
+        if (int rc = stream_pin[1].ensure(PIECE)) return rc;
+        if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (!fill_done) DSM_HIP(hipEventCreateWithFlags(&fill_done, hipEventDisableTiming));
+        DSM_HIP(hipEventRecord(fill_done, st));
+        DSM_HIP(hipStreamWaitEvent(copy_stream, fill_done, 0));
         int rc = 0;
-        for (u64 o = 0; o < total && !rc; o += PIECE) {
-            size_t nb = (size_t)((total - o) < PIECE ? (total - o) : PIECE);
-            hipError_t e = hipMemcpyAsync(h_piece, d_out + o, nb, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        const u64 npieces = (total + PIECE - 1) / PIECE;
+        auto piece_bytes = [&](u64 k) { return (size_t)((total - k * PIECE) < PIECE ? (total - k * PIECE) : PIECE); };
+        if (npieces) DSM_HIP(hipMemcpyAsync(stream_pin[0].p, d_out, piece_bytes(0), hipMemcpyDeviceToHost, copy_stream));
+        for (u64 k = 0; k < npieces && !rc; ++k) {
+            hipError_t e = hipStreamSynchronize(copy_stream);  // piece k has landed
             if (e != hipSuccess) { rc = fail(DSM_E_HIP, hipGetErrorString(e)); break; }
-            if (sink && sink(ctx, h_piece, nb)) rc = fail(DSM_E_SINK, "byte sink failed");
+            if (k + 1 < npieces)
+                DSM_HIP(hipMemcpyAsync(stream_pin[(k + 1) & 1].p, d_out + (k + 1) * PIECE, piece_bytes(k + 1), hipMemcpyDeviceToHost, copy_stream));
+            if (sink && sink(ctx, (const u8*)stream_pin[k & 1].p, piece_bytes(k))) rc = fail(DSM_E_SINK, "byte sink failed");
         }
+        if (rc) (void)hipStreamSynchronize(copy_stream);
         return rc;
     }
-    PinBuf stream_pin;
+    PinBuf stream_pin[2];
 };
 
 static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {

@@ -131,3 +131,31 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
     for p in prefixes:
         want = sum(ix.enumerate(n, p, fmin=m["fmin"])[1][0] for ix, n in zip(oidx, names))
         assert sum(reported[p]) == want
+
+
+def test_turn_gate_interleaves_lanes_deterministically():
+    """Two lane threads with different numbers of collectives: the global order is strict round-robin while both are active."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+    from pydsm.dist import TurnGate
+    for trial in range(20):
+        gate = TurnGate(2)
+        log = []
+
+        def lane(j, n):
+            import random
+            import time
+            gate.begin(j)
+            for k in range(n):
+                time.sleep(random.random() * 0.002)
+                gate.acquire(j)
+                log.append((j, k))
+                gate.release(j)
+            gate.retire(j)
+        ts = [threading.Thread(target=lane, args=(0, 5)), threading.Thread(target=lane, args=(1, 9))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(10)
+        assert log == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3), (0, 4), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8)]
+        gate.reset()
