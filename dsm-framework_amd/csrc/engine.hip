@@ -41,22 +41,66 @@ struct RankCache {
     Blk16 r, r1;
 };
 
-// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
-// Positions are visited in ascending order, so the held block changes at most a few times; the block of
-// the interval's end was requested up front (its latency overlaps the first block's).
-template <typename P>
-__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache& rc, u64 x, P out[4], u32& lines) {
+__device__ __forceinline__ void rc_select(const DevIndex& ix, RankCache& rc, u64 x, u32& lines) {
     u64 bi = x >> BLK_SHIFT;
     if (bi != rc.bi) {
         if (bi == rc.b1) rc.r = rc.r1;
         else { load_blk(ix.blk, bi, rc.r); ++lines; }
         rc.bi = bi;
     }
+}
+
+// occurrences of A,C,G,T among the first `off` symbols of a block with four population counts:
+// |base|, |base & p1| = G+T, |base & p0| = C+T, |base & p1 & p0| = T
+__device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4]) {
+    u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
+    u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+    u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
+    u64 h1a = ba & r.p1a, h1b = bb & r.p1b;
+    u32 tot = __popcll(ba) + __popcll(bb);
+    u32 s1 = __popcll(h1a) + __popcll(h1b);
+    u32 s0 = __popcll(ba & r.p0a) + __popcll(bb & r.p0b);
+    u32 s3 = __popcll(h1a & r.p0a) + __popcll(h1b & r.p0b);
+    out[3] = s3; out[2] = s1 - s3; out[1] = s0 - s3; out[0] = tot - s1 - s0 + s3;
+}
+
+// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
+template <typename P>
+__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache& rc, u64 x, P out[4], u32& lines) {
+    rc_select(ix, rc, x, lines);
     u32 c4[4];
-    blk_counts(rc.r, (u32)(x & (BLK_SYMS - 1)), c4);
+    blk_counts4(rc.r, (u32)(x & (BLK_SYMS - 1)), c4);
     const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + rc.r.cnt[c] + c4[c]);
+}
+
+template <typename P>
+__device__ __forceinline__ void rank4_blk(const DevIndex& ix, const Blk16& r, u64 x, P out[4]) {
+    u32 c4[4];
+    blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
+    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + r.cnt[c] + c4[c]);
+}
+
+// the same for the bases selected by `want` only (the children that survive): one masked popcount per base
+template <typename P>
+__device__ __forceinline__ void rank_sel(const DevIndex& ix, RankCache& rc, u64 x, u32 want, P out[4], u32& lines) {
+    rc_select(ix, rc, x, lines);
+    const Blk16& r = rc.r;
+    const u32 off = (u32)(x & (BLK_SYMS - 1));
+    u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
+    u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+    u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
+    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (!((want >> c) & 1u)) continue;
+        u64 xa = ba & ((c & 2) ? r.p1a : ~r.p1a) & ((c & 1) ? r.p0a : ~r.p0a);
+        u64 xb = bb & ((c & 2) ? r.p1b : ~r.p1b) & ((c & 1) ? r.p0b : ~r.p0b);
+        out[c] = (P)(sb[c] + r.cnt[c] + (u32)(__popcll(xa) + __popcll(xb)));
+    }
 }
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -100,13 +144,15 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     if (i < a.F) r = rp[i];
     const bool live = r != DEAD;
     P sp = 1, ep = 0, emin[4], emax[4];
-    P Rsp[4], Rep[4], Rlo[4][4], Rhi[4][4];
+    P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
     u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
+    RankCache rc;
+    rc.bi = ~0ull;
+    rc.b1 = ~0ull;
     if (live) {
         sp = rec[r];
         ep = rec[(size_t)a.cap + r];
-        RankCache rc;
         rc.bi = (u64)sp >> BLK_SHIFT;
         rc.b1 = ((u64)ep + 1) >> BLK_SHIFT;
         load_blk(ix.blk, rc.bi, rc.r);  // both ends of the interval are requested before anything waits
@@ -129,16 +175,10 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
             // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
             mycode = matches ? 1u + lc : (any ? 5u : 0u);
         }
-        rank4<P>(ix, rc, (u64)sp, Rsp, lines);  // LF(c, sp-1)
+        rank4_blk<P>(ix, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
         const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (emin[k] <= emax[k]) {
-                rank4<P>(ix, rc, (u64)emin[k], Rlo[k], lines);
-                rank4<P>(ix, rc, (u64)emax[k] + 1, Rhi[k], lines);
-            }
-        }
-        rank4<P>(ix, rc, (u64)ep + 1, Rep, lines);  // LF(c, ep)
+        if (rc.b1 != ~0ull) rank4_blk<P>(ix, rc.r1, (u64)ep + 1, Rep);  // LF(c, ep); r keeps the first block for the ext pass
+        else rank4_blk<P>(ix, rc.r, (u64)ep + 1, Rep);
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         if (single && a.allowed) n_rank += a.access_cost[lcode];
 #pragma unroll
@@ -160,15 +200,24 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     __shared__ u64 red[4][4];
     const u32 k = __popc(present);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 inc = k;
+    // exclusive prefix of k (0..4) inside the wave from three ballots (bit-sliced), no LDS traffic
+    u32 excl = 0, wsum = 0;
+    {
+        const u64 lt = (1ull << lane) - 1;
 #pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        u32 o = __shfl_up(inc, dd, 64);
-        if (lane >= dd) inc += o;
+        for (int b = 0; b < 3; ++b) {
+            const u64 m = __ballot((k >> b) & 1u);
+            excl += (u32)__popcll(m & lt) << b;
+            wsum += (u32)__popcll(m) << b;
+        }
     }
-    if (lane == 63) wtot[w] = inc;
-    u64 s0 = wave_sum_u64((u64)k), s1 = wave_sum_u64(n_lf), s2 = wave_sum_u64(n_rank), s3 = wave_sum_u64((u64)lines);
-    if (lane == 0) { red[w][0] = s0; red[w][1] = s1; red[w][2] = s2; red[w][3] = s3; }
+    if (lane == 0) wtot[w] = wsum;
+    // the four counters travel as one packed word: k <= 4, lines <= 12, lf <= 40, rank-ops <= 160 per lane
+    u64 packed = (u64)k | ((u64)lines << 10) | (n_lf << 22) | (n_rank << 36);
+    packed = wave_sum_u64(packed);
+    if (lane == 0) {
+        red[w][0] = packed & 0x3FF; red[w][3] = (packed >> 10) & 0xFFF; red[w][1] = (packed >> 22) & 0x3FFF; red[w][2] = packed >> 36;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
@@ -180,27 +229,61 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
     }
     __syncthreads();
-    u32 pos = sbase + (inc - k);
+    u32 pos = sbase + excl;
     for (int q = 0; q < w; ++q) pos += wtot[q];
     if (i < a.F) {
         if (present) {
             tpos[i] = pos;  // children of one parent get consecutive handles: child c is at tpos + #present children before c
+            // handle of every surviving child, interval fields first
+            u32 hnd[4];
+            {
+                u32 q = pos;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (!((present >> c) & 1u)) continue;
-                const P nsp = Rsp[c], nep = Rep[c] - 1;
-                const bool fits = pos < a.cap;  // overflow is detected by the host from *alloc
-                if (fits) { out[pos] = nsp; out[(size_t)a.cap + pos] = nep; }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    P cmin = 1, cmax = 0;
-                    if (emin[kk] <= emax[kk]) {  // EnumerateQuery.cpp:44-55
-                        P lo = Rlo[kk][c], hi = Rhi[kk][c] - 1;
-                        if (lo <= hi) { cmin = lo; cmax = hi; }
+                for (int c = 0; c < 4; ++c) {
+                    hnd[c] = q;
+                    if ((present >> c) & 1u) {
+                        if (q < a.cap) { out[q] = Rsp[c]; out[(size_t)a.cap + q] = Rep[c] - 1; }  // overflow is detected by the host from *alloc
+                        ++q;
                     }
-                    if (fits) { out[(size_t)(2 + kk) * a.cap + pos] = cmin; out[(size_t)(6 + kk) * a.cap + pos] = cmax; }
                 }
-                ++pos;
+            }
+            // left-extension intervals of the children (EnumerateQuery.cpp:44-55): LF at both ends of every non-empty
+            // parent ext, only for the bases that survive.  Ends that coincide with sp / ep+1 or with the previous
+            // position (adjacent ext intervals share them) are not evaluated again.
+            u64 lastx = ~0ull;
+            P lastv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bool nonempty_ext = emin[kk] <= emax[kk];
+                P lo[4], hi[4];
+                if (nonempty_ext) {
+                    const u64 xl = (u64)emin[kk], xh = (u64)emax[kk] + 1;
+                    if (xl == (u64)sp) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lo[c] = Rsp[c];
+                    } else if (xl == lastx) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lo[c] = lastv[c];
+                    } else {
+                        rank_sel<P>(ix, rc, xl, present, lo, lines);
+                    }
+                    if (xh == (u64)ep + 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hi[c] = Rep[c];
+                    } else {
+                        rank_sel<P>(ix, rc, xh, present, hi, lines);
+                        lastx = xh;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lastv[c] = hi[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!((present >> c) & 1u)) continue;
+                    P cmin = 1, cmax = 0;
+                    if (nonempty_ext && lo[c] <= hi[c] - 1) { cmin = lo[c]; cmax = hi[c] - 1; }
+                    if (hnd[c] < a.cap) { out[(size_t)(2 + kk) * a.cap + hnd[c]] = cmin; out[(size_t)(6 + kk) * a.cap + hnd[c]] = cmax; }
+                }
             }
         }
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
