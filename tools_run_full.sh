@@ -1,7 +1,11 @@
 set -e
 R=$GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $R/gpurun_out/t_all.log 2>&1 || true
+tail -3 $R/gpurun_out/t_all.log
+python $R/bench.py 2> $R/gpurun_out/bench_final.err | tee $R/gpurun_out/bench_final.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -E "^\s*Counter_Name|Name\s*:" | sed 's/.*:\s*//' | sort -u | tr '\n' ' ' > $R/gpurun_out/all_counters.txt || true
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/pmc4_sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_sq.log 2>&1 || echo sqfail
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmc4_tc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_tc.log 2>&1 || echo tcfail
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01f -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc6_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc6_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmc6_l2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_l2.log 2>&1 || true
 echo done
