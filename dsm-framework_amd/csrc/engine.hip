@@ -1029,6 +1029,14 @@ struct Emitter {
     }
 };
 
+// emission-side allocations (candidates, tuple assembly) come from their own arena in multi-rank runs, so that the structure
+// arena is used identically on every rank and only the emission side can differ (owner-only emission)
+#define EARENA_GET(var, T, n)                                                                       \
+    do {                                                                                            \
+        (var) = ea->template get<T>(n);                                                             \
+        if (!(var)) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes"); \
+    } while (0)
+
 template <typename P>
 class Engine {
   public:
@@ -1062,6 +1070,8 @@ class Engine {
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, then u64 totals
     std::vector<void*> owned;
     Arena arena;
+    Arena earena;          // multi-rank: emission-side allocations
+    Arena* ea = nullptr;   // &earena, or &arena in single-process runs
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evpool;
     dsm_stats stats;
@@ -1191,7 +1201,8 @@ class Engine {
             used = free_b - f2;
         }
         u64 arena_b = budget > used ? budget - used : 0;
-        if (arena_b < (64u << 20)) arena_b = 64u << 20;
+        const u64 floor_b = p.arena_bytes ? (1u << 20) : (64u << 20);  // an explicit budget is honoured down to 1 MiB
+        if (arena_b < floor_b) arena_b = floor_b;
         if (world > 1) {
             u64 agreed = 0;
             if (int rc = agree_min(arena_b, &agreed)) return rc;
@@ -1199,6 +1210,13 @@ class Engine {
         }
         if (int rc = dalloc(arena.base, arena_b)) return rc;
         arena.cap = arena_b;
+        ea = &arena;
+        if (world > 1 && !stream_mode) {  // 60 % structure (identical on every rank), 40 % emission
+            arena.cap = (size_t)(arena_b * 0.6) & ~(size_t)255;
+            earena.base = arena.base + arena.cap;
+            earena.cap = arena_b - arena.cap;
+            ea = &earena;
+        }
         DSM_HIP(hipEventCreate(&ev0));
         DSM_HIP(hipEventCreate(&ev1));
         return 0;
@@ -1255,6 +1273,9 @@ class Engine {
                 return fail(DSM_E_INVAL, "prefix must be over A,C,G,T");  // anything else has an empty LF interval: nothing to send
         DSM_HIP(hipSetDevice(device));
         arena.off = 0;
+        earena.off = 0;
+        bool emitting = emit;       // cleared when this rank's emission side runs out of memory in a multi-rank run
+        bool emit_failed = false;
         std::vector<LevelHost> L;
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
@@ -1433,37 +1454,10 @@ class Engine {
                 }
             }
             // ---- output predicates for the nodes of THIS level (their children are known now) -----
-            if (!stream_mode && emit && depth >= 1 && depth >= emit_lo && depth <= emit_hi) {
-                FilterArgs fa;
-                fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
-                fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
-                const Xchg& xp = x;  // the columns of THIS level's nodes arrived with this level's exchange
-                ARENA_GET(me.cand_flag, u8, F);
-                const bool one = d == 1;
-                hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
-                                   me.cand_flag, one ? (u64*)nullptr : cand_key);
-                u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
-                if (one) {
-                    exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
-                    DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
-                } else {
-                    exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-                    DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
-                }
-                DSM_HIP(hipStreamSynchronize(st));
-                u64 tot = 0;
-                memcpy(&tot, h_totals + 48, sizeof tot);
-                me.ncand = (u32)(tot & 0xFFFFFFFFu);
-                me.npairs = one ? me.ncand : (u32)(tot >> 32);
-                if (me.ncand) {
-                    ARENA_GET(me.cand_node, u32, me.ncand);
-                    ARENA_GET(me.cand_poff, u32, me.ncand);
-                    ARENA_GET(me.ids, u32, me.npairs);
-                    ARENA_GET(me.freqs, u64, me.npairs);
-                    hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag, one ? (const u64*)nullptr : cand_keyscan, idx32,
-                                       me.cand_node, me.cand_poff, me.ids, me.freqs);
-                }
-                stats.candidates += me.ncand;
+            if (!stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi) {
+                int erc = emit_level(me, F, depth, x, cur, order_mode);
+                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }  // agreed on at the end of the prefix
+                else if (erc) return erc;
             }
             DSM_HIP(hipGetLastError());
             stats.union_nodes += depth >= 1 ? F : 0;
@@ -1479,8 +1473,22 @@ class Engine {
         }
         const u32 nlev = (u32)L.size();  // levels 0..nlev-1, level l holds the nodes of depth l
 
-        int rc = stream_mode ? finish_stream(L, nlev, bsink, ctx) : (emit ? finish_mine(L, nlev, tsink, ctx) : 0);
-        if (rc) return rc;
+        bool ready = false;
+        if (stream_mode) {
+            if (int rc = finish_stream(L, nlev, bsink, ctx)) return rc;
+        } else {
+            if (emitting) {
+                int rc = finish_mine(L, nlev, tsink, ctx, &ready);
+                if (rc == DSM_E_CAPACITY && world > 1) { emit_failed = true; ready = false; }
+                else if (rc) return rc;
+            }
+            if (world > 1) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
+                u64 ok = emit_failed ? 0 : 1, all_ok = 0;
+                if (int rc = agree_min(ok, &all_ok)) return rc;
+                if (!all_ok) return fail(DSM_E_CAPACITY, "device arena exhausted on a rank: use a longer prefix or a larger arena_bytes");
+            }
+            if (ready) emitter.submit();
+        }
 
         DSM_HIP(hipEventRecord(ev1, st));
         DSM_HIP(hipStreamSynchronize(st));
@@ -1508,8 +1516,46 @@ class Engine {
         return 0;
     }
 
+    // ---- output predicates and candidate store for the nodes of one level (their children are known) ----
+    int emit_level(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
+        FilterArgs fa;
+        fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
+        fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
+        EARENA_GET(me.cand_flag, u8, F);
+        const bool one = d == 1;
+        hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
+                           me.cand_flag, one ? (u64*)nullptr : cand_key);
+        u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
+        if (one) {
+            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
+            DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
+        } else {
+            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
+            DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+        }
+        DSM_HIP(hipStreamSynchronize(st));
+        u64 tot = 0;
+        memcpy(&tot, h_totals + 48, sizeof tot);
+        me.ncand = (u32)(tot & 0xFFFFFFFFu);
+        me.npairs = one ? me.ncand : (u32)(tot >> 32);
+        if (me.ncand) {
+            u32 nc = me.ncand;
+            me.ncand = 0;  // stays 0 if the store does not fit: the level then has no usable candidates
+            EARENA_GET(me.cand_node, u32, nc);
+            EARENA_GET(me.cand_poff, u32, nc);
+            EARENA_GET(me.ids, u32, me.npairs);
+            EARENA_GET(me.freqs, u64, me.npairs);
+            me.ncand = nc;
+            hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag,
+                               one ? (const u64*)nullptr : cand_keyscan, idx32, me.cand_node, me.cand_poff, me.ids, me.freqs);
+        }
+        stats.candidates += me.ncand;
+        return 0;
+    }
+
     // ---- mine: post-order ranks of the candidates, tuple assembly, exact entropy on the host ------
-    int finish_mine(std::vector<LevelHost>& L, u32 nlev, dsm_tuple_sink sink, void* ctx) {
+    // Prepares everything up to the copies into the pinned set; the caller submits the set to the emitter (*ready).
+    int finish_mine(std::vector<LevelHost>& L, u32 nlev, dsm_tuple_sink sink, void* ctx, bool* ready) {
         u64 ncand_total = 0;
         for (u32 l = 1; l < nlev; ++l) ncand_total += L[l].ncand;
         if (ncand_total == 0) return 0;
@@ -1517,23 +1563,23 @@ class Engine {
         const u32 nt = (u32)ncand_total;
         // bottom-up: candidates in subtree
         for (u32 l = nlev; l-- > 1;) {
-            ARENA_GET(L[l].sub, u32, L[l].n);
+            EARENA_GET(L[l].sub, u32, L[l].n);
             const u32* child_sub = l + 1 < nlev ? L[l + 1].sub : nullptr;
             if (!L[l].cand_flag) {  // level outside the emitted depth range: no candidates of its own
-                ARENA_GET(L[l].cand_flag, u8, L[l].n);
+                EARENA_GET(L[l].cand_flag, u8, L[l].n);
                 DSM_HIP(hipMemsetAsync(L[l].cand_flag, 0, L[l].n, st));
             }
             hipLaunchKernelGGL((up_kernel<u32, u8>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
         }
         // top-down: start offsets, two rolling arrays
         u32 *t_level, *t_cidx;
-        ARENA_GET(t_level, u32, nt);
-        ARENA_GET(t_cidx, u32, nt);
+        EARENA_GET(t_level, u32, nt);
+        EARENA_GET(t_cidx, u32, nt);
         u32 maxn = 1;
         for (u32 l = 0; l < nlev; ++l) maxn = L[l].n > maxn ? L[l].n : maxn;
         u32* startbuf[2];
-        ARENA_GET(startbuf[0], u32, maxn);
-        ARENA_GET(startbuf[1], u32, maxn);
+        EARENA_GET(startbuf[0], u32, maxn);
+        EARENA_GET(startbuf[1], u32, maxn);
         DSM_HIP(hipMemsetAsync(startbuf[0], 0, sizeof(u32), st));
         for (u32 l = 0; l + 1 < nlev; ++l) {
             u32* s_cur = startbuf[l & 1];
@@ -1550,7 +1596,7 @@ class Engine {
             lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = L[l].ncand; lv[l].npairs = L[l].npairs;
         }
         LevelDev* d_lv;
-        ARENA_GET(d_lv, LevelDev, nlev);
+        EARENA_GET(d_lv, LevelDev, nlev);
         DSM_HIP(hipMemcpyAsync(d_lv, lv.data(), nlev * sizeof(LevelDev), hipMemcpyHostToDevice, st));
         // The tuple arrays live in the emit set (not the arena): the copy stream drains them to pinned memory while the
         // compute stream already expands the next prefix.
@@ -1560,15 +1606,15 @@ class Engine {
         if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         if (!fill_done) DSM_HIP(hipEventCreateWithFlags(&fill_done, hipEventDisableTiming));
         u32 *plen, *npair;
-        ARENA_GET(plen, u32, nt);
-        ARENA_GET(npair, u32, nt);
+        EARENA_GET(plen, u32, nt);
+        EARENA_GET(npair, u32, nt);
         if (int rc = E.dev[0].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.dev[1].ensure(((size_t)nt + 1) * 4)) return rc;
         u32* path_off = (u32*)E.dev[0].p;
         u32* pair_off = (u32*)E.dev[1].p;
         hipLaunchKernelGGL(tuple_size_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, plen, npair);
         u32* stmp;
-        ARENA_GET(stmp, u32, scan_tmp_elems(nt) + 8);
+        EARENA_GET(stmp, u32, scan_tmp_elems(nt) + 8);
         exclusive_scan<u32, u32>(plen, path_off, nt, stmp, d_totals, st);
         exclusive_scan<u32, u32>(npair, pair_off, nt, stmp, d_totals + 1, st);
         DSM_HIP(hipMemcpyAsync(path_off + nt, d_totals, sizeof(u32), hipMemcpyDeviceToDevice, st));
@@ -1599,7 +1645,7 @@ class Engine {
         DSM_HIP(hipEventRecord(E.ready, copy_stream));
         E.nt = nt;
         emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
-        emitter.submit();
+        *ready = true;
         return 0;
     }
     hipStream_t copy_stream = nullptr;

@@ -88,6 +88,11 @@ def _gpu_worker(rank, world, port, q, fmis, prefixes, kw):
             parts.append(int(b.ntuples))
         text, st = m.mine_many(prefixes, on_batch=on_batch)
         out.append(("owner", text, st.reported, st.union_nodes, st.pair_order_exact))
+    # a budget so small that levels / the owner's candidate store overflow: every rank must split the same prefixes
+    with pydsm.Miner(idx, world_size=world, rank=rank, allgather=ex.allgather, exchange=ex.params(), emit_owner_only=True,
+                     arena_bytes=(5 << 20) * nloc, **kw) as m:
+        text, st = m.mine_many(prefixes)
+        out.append(("owner-split", text, st.splits, st.union_nodes, st.pair_order_exact))
     q.put((rank, out, ex.calls))
     for ix in idx:
         ix.close()
@@ -116,17 +121,22 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
         p.join(60)
     # every rank computes the same union trie; tuples must equal the reference server's stdout
     reported = {}
+    splits = []
     for rank, out, calls in res:
         assert calls > 0
         for p, text, rep, union, exact in out:
             assert exact == 1
-            if p == "owner":
+            if p in ("owner", "owner-split"):
                 mine = b"".join(golden.server_out(setname, cfg, q) for k, q in enumerate(prefixes) if k % world == rank)
-                assert text == mine, (rank, "owner-only")
+                assert text == mine, (rank, p)
+                if p == "owner-split":
+                    splits.append(rep)
                 continue
             assert text == golden.server_out(setname, cfg, p), (rank, p)
             reported.setdefault(p, []).append(rep)
     # per-rank `reported` is that rank's own sample: the sum equals the oracle's client total
+    assert len(set(splits)) == 1  # the same number of splits on every rank
+    assert splits[0] > 0, "the tiny budget was meant to force prefix splits"
     oidx = [orc.Index(f) for f in fmis]
     for p in prefixes:
         want = sum(ix.enumerate(n, p, fmin=m["fmin"])[1][0] for ix, n in zip(oidx, names))
