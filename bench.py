@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--wide", action="store_true", help="force 64-bit positions (the code path of n > 2^32, BASELINE configs[3])")
     ap.add_argument("--stream-mode", action="store_true", help="time the wire-stream path (dsm_enumerate, the TCP drop-in client) instead of mining")
     ap.add_argument("--lanes", type=int, default=0, help="independent prefix lanes (own stream, own communicator) that overlap one lane's "
-                    "all-gather with the other's kernels; default 1")
+                    "all-gather with the other's kernels; default 1 (N=1) / 2 (N>1)")
     ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
     ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
     return ap.parse_args()
@@ -149,10 +149,11 @@ def main():
     # one collective per frontier level, nothing else on the data path.  A lane = one miner with its own HIP stream and
     # (multi-rank) its own communicator; lanes take the prefixes round-robin and run concurrently, so one lane's
     # collective overlaps the other lane's kernels.
-    # Default is one lane: two lanes (two communicators driven from two threads, collectives interleaved deterministically by
-    # pydsm.dist.TurnGate) hide the all-gather behind the other lane's kernels and have been rehearsed with gloo on one card,
-    # but not yet with RCCL on a multi-GPU node; opt in with --lanes 2 or DSM_BENCH_LANES=2.
-    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1"))
+    # Multi-rank runs use two lanes so that one lane's all-gather overlaps the other lane's kernels.  Both lanes use the ONE
+    # default communicator; pydsm.dist.TurnGate makes them enqueue their collectives in strict alternation, i.e. in the same
+    # order on every rank (each lane issues the same number of collectives everywhere because every rank walks the same
+    # union trie).  DSM_BENCH_LANES / --lanes override.
+    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 else "2"))
     nlanes = max(1, min(nlanes, len(prefixes)))
     lanes = []
     gate = None
@@ -164,7 +165,7 @@ def main():
         allgather = exchange = None
         if world > 1:
             from pydsm.dist import Exchange
-            group = dist.new_group(ranks=list(range(world))) if nlanes > 1 else None
+            group = None  # the default communicator, shared by the lanes
             lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
             allgather, exchange = lane["ex"].allgather, lane["ex"].params()
         arena = 0
@@ -172,7 +173,7 @@ def main():
             free_b, _ = torch.cuda.mem_get_info(dev)
             sharing = (world + ndev - 1) // max(1, ndev)
             want = (256 << 20) + 900 * sum(x.n for x in ixs) * world
-            arena = int(min(want, free_b * 0.8 / (nlanes - j) / sharing))
+            arena = int(min(want, free_b * 0.7 / (nlanes - j) / sharing))
         lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
                                     allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
                                     emit_owner_only=world > 1, arena_bytes=arena, wide=1 if args.wide else 0,
@@ -215,6 +216,11 @@ def main():
                     tot["cand"] += st.candidates
         except Exception as e:  # noqa: BLE001
             errs.append(e)
+            if world > 1:  # the other ranks are blocked in a collective: fail the whole job instead of hanging it
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(13)
         finally:
             if gate is not None:
                 gate.retire(lanes.index(lane))
@@ -239,6 +245,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and gate is not None:
+        def dump_order():
+            with open(os.path.join(ROOT, "gpurun_out", "order_rank%d.txt" % rank), "w") as f:
+                for it in gate.log:
+                    f.write("%d %d\n" % it)
+        import atexit
+        atexit.register(dump_order)
+        import threading as _th
+        _t = _th.Timer(100, dump_order)
+        _t.daemon = True
+        _t.start()
     if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1:
         import atexit
         atexit.register(lambda: print("TRACE rank %d: %s" % (rank, lanes[0]["ex"].trace[:60]), file=sys.stderr, flush=True))

@@ -18,6 +18,7 @@ class TurnGate:
         self.cv = threading.Condition()
         self.active = [True] * nlanes
         self.turn = 0
+        self.log = [] if __import__('os').environ.get('DSM_TRACE_EXCHANGE') else None
 
     def _advance(self):
         n = len(self.active)
@@ -99,6 +100,8 @@ class Exchange:
         if self.gate is not None:
             self.gate.acquire(self.lane)
             try:
+                if self.gate.log is not None:
+                    self.gate.log.append((self.lane, int(nbytes)))
                 self._allgather(nbytes, off)
             finally:
                 self.gate.release(self.lane)
