@@ -123,6 +123,7 @@ struct ExpandArgs {
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
+    u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
 };
@@ -136,7 +137,7 @@ template <typename P>
 __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
                                                      u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ valf,
                                                      u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
-                                                     u32* __restrict__ blockcnt) {
+                                                     u32* __restrict__ blockcnt, unsigned long long* __restrict__ childmax) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u64 n_lf = 0, n_rank = 0;
     u32 lines = 0;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     P sp = 1, ep = 0, emin[4], emax[4];
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
+    u64 maxchild = 0; // largest frequency among the surviving children (decides the next level's column width)
     u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
     RankCache rc;
     rc.bi = ~0ull;
@@ -189,7 +191,11 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                 if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
                 if (nonempty) {
                     if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
-                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) present |= 1u << c;  // EnumerateQuery.cpp:186
+                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
+                        present |= 1u << c;
+                        const u64 cfq = (u64)(nep - nsp) + 1;
+                        maxchild = cfq > maxchild ? cfq : maxchild;
+                    }
                 }
             }
         }
@@ -212,6 +218,12 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         }
     }
     if (lane == 0) wtot[w] = wsum;
+    {
+        u64 m = maxchild;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { u64 o = __shfl_xor(m, dd, 64); m = o > m ? o : m; }
+        if (lane == 0 && m >= 65535) atomicMax(childmax, (unsigned long long)m);  // only wide values matter (and they are rare)
+    }
     // the four counters travel as one packed word: k <= 4, lines <= 12, lf <= 40, rank-ops <= 160 per lane
     u64 packed = (u64)k | ((u64)lines << 10) | (n_lf << 22) | (n_rank << 36);
     packed = wave_sum_u64(packed);
@@ -287,7 +299,8 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
             }
         }
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
-        valf[i] = live ? (P)(ep - sp + 1) : (P)0;
+        if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
+        else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
         pl[i] = (u8)(present | (mycode << 4));
     }
 }
@@ -300,6 +313,7 @@ struct Xchg {
     u32 nlocal;
     u32 d;        // total samples = world * nlocal
     u64 F;        // nodes of the level
+    u32 fb;       // bytes per frequency entry: 2 when every frequency of the level is below 65535, else sizeof(P)
 };
 __device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
     if (x.nlocal == 1) { r = g; l = 0; }          // one sample per rank (multi-GPU runs)
@@ -311,13 +325,14 @@ __device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
     const u8* rb = x.base + (u64)r * x.bpr;
+    if (x.fb == 2) return (P)reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v];
     return reinterpret_cast<const P*>(rb)[(u64)l * x.F + v];
 }
 template <typename P>
 __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
-    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * sizeof(P);
+    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
     return rb[(u64)l * x.F + v];
 }
 
@@ -337,7 +352,7 @@ __device__ __forceinline__ void slots_eval8(const Xchg& x, u64 u0, u32 nTs[ADV_S
     const bool two = u0 + 1 < x.F;
     const u32 world = x.d / x.nlocal;
     for (u32 r = 0; r < world; ++r) {
-        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * sizeof(P);
+        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
         for (u32 l = 0; l < x.nlocal; ++l) {
             const u8* q = pb + (u64)l * x.F + u0;
             u32 m = (u32)(q[0] & 15) | (two ? (u32)(q[1] & 15) << 4 : 0u);
@@ -1068,6 +1083,7 @@ class Engine {
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, then u64 totals
+    u64* h_childmax = nullptr;  // pinned: one per rank
     std::vector<void*> owned;
     Arena arena;
     Arena earena;          // multi-rank: emission-side allocations
@@ -1082,6 +1098,7 @@ class Engine {
     ~Engine() {
         for (void* p : owned) (void)hipFree(p);
         if (h_totals) (void)hipHostFree(h_totals);
+        if (h_childmax) (void)hipHostFree(h_childmax);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
@@ -1140,11 +1157,11 @@ class Engine {
         if (fc > fbound) fc = fbound;
         if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         Fcap = (u32)fc;
-        bpr_cap = ((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull;
+        bpr_cap = (((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull) + 16;
         if (p.exchange_send && p.exchange_recv && world > 1) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
             // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
-            u64 cap_slots = (p.exchange_bytes - 16) / ((u64)nlocal * (sizeof(P) + 1));
+            u64 cap_slots = (p.exchange_bytes - 32) / ((u64)nlocal * (sizeof(P) + 1));
             if (cap_slots < Fcap) Fcap = (u32)cap_slots;
             bpr_cap = p.exchange_bytes;
             xsend = (u8*)p.exchange_send;
@@ -1194,6 +1211,7 @@ class Engine {
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 64 * sizeof(u32)));
+        DSM_HIP(hipHostMalloc((void**)&h_childmax, (size_t)(world > 0 ? world : 1) * sizeof(u64)));
         size_t used = 0;
         {
             size_t f2 = 0, t2 = 0;
@@ -1324,6 +1342,9 @@ class Engine {
         const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);  // (declared before the level loop: used by seed/capture)
         stats.pair_order_exact = 1;
 
+        // Width of the frequency column of the level about to be exchanged.  Every rank derives it from the same number: the
+        // largest frequency any sample has at that level, carried in the previous level's exchange (the root level is wide).
+        bool w16 = false;
         int cur = 0;      // ping-pong index of the current level (rec, rp, nT, order)
         int xcur = 0;     // exchange buffer that will receive the current level's children
         u32 F = 1;
@@ -1331,12 +1352,16 @@ class Engine {
         while (true) {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
-            const u64 bpr = ((u64)nlocal * F * (sizeof(P) + 1) + 15) & ~15ull;  // ranks start 16-byte aligned
+            const u32 fb = w16 ? 2u : (u32)sizeof(P);
+            // per rank: [nlocal][F] frequencies, [nlocal][F] bytes, padding, then one u64: largest child frequency of this level
+            const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
             u8* send = world > 1 ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
-            ea.F = F; ea.cap = Fcap; ea.fmin = prm.fmin;
+            ea.F = F; ea.cap = Fcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
+            unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send + bpr - 16);
+            DSM_HIP(hipMemsetAsync(d_childmax, 0, 16, st));
             if (depth < prefix.size()) {
                 const char* q = strchr(bases, prefix[depth]);
                 ea.allowed = 1u << (q - bases);
@@ -1353,10 +1378,10 @@ class Engine {
                 const IndexMeta& m = idx[s]->meta;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
-                P* cf = reinterpret_cast<P*>(send) + (size_t)s * F;                        // this sample's frequency column
-                u8* cl = send + (size_t)nlocal * F * sizeof(P) + (size_t)s * F;           // children nibble | left char << 4
+                P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);                  // this sample's frequency column
+                u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;                  // children nibble | left char << 4
                 hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
-                                   tpos[s], cf, cl, ea, d_counters, d == 1 ? blockcnt : (u32*)nullptr);
+                                   tpos[s], cf, cl, ea, d_counters, d == 1 ? blockcnt : (u32*)nullptr, d_childmax);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
@@ -1367,6 +1392,7 @@ class Engine {
                 if (rc) return fail(DSM_E_SINK, "allgather callback failed");
             }
             Xchg x = xview(xcur, F, bpr);
+            x.fb = fb;
             // ---- union frontier of the next level -------------------------------------------------
             LevelHost& me = L[depth];
             LevelHost child;
@@ -1401,8 +1427,14 @@ class Engine {
             }
             DSM_HIP(hipMemcpyAsync(h_totals, d_totals, sizeof(u32), hipMemcpyDeviceToHost, st));
             DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, MAX_LOCAL * sizeof(u32), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipMemcpy2DAsync(h_childmax, sizeof(u64), xrecv[xcur] + bpr - 16, (size_t)bpr, sizeof(u64), (size_t)world, hipMemcpyDeviceToHost, st));
             DSM_HIP(hipStreamSynchronize(st));
             const u32 Fn = h_totals[0];
+            {
+                u64 mx = 0;
+                for (int r = 0; r < world; ++r) mx = h_childmax[r] > mx ? h_childmax[r] : mx;
+                w16 = mx < 65535;  // the next level's frequencies all fit 16 bits
+            }
             for (int s = 0; s < nlocal; ++s)
                 if (h_totals[8 + s] > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
