@@ -89,3 +89,37 @@ def test_whole_pass_invariants(big):
     with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m:
         _, gst = m.mine("G", text=False)
     assert sst.reported == gst.reported and nb > 4 * sst.reported
+
+
+def test_three_midsize_samples_against_oracle():
+    """d = 3 at a size where the top levels need wide frequency columns and the rest 16-bit ones (the toy fixtures never
+    leave the 16-bit regime): GPU tuples == oracle's on whole one-letter prefixes restricted by maxdepth, and on deep 7-mers."""
+    import torch
+    import orc
+    import pydsm
+    from pydsm import builder
+    d = os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench")
+    os.makedirs(d, exist_ok=True)
+    paths = []
+    for s in range(3):
+        p = os.path.join(d, "mid-%d.fmi" % s)
+        if not os.path.exists(p):
+            codes = builder.synth_reads(100 + s, 200000, 100, 1000000, 0.005, device="cuda", private_frac=0.05)
+            builder.build_from_codes(codes, p + ".tmp")
+            os.replace(p + ".tmp", p)
+        paths.append(p)
+    torch.cuda.empty_cache()
+    idx = [pydsm.Index(p) for p in paths]
+    oidx = [orc.Index(p) for p in paths]
+    names = [ix.name for ix in idx]
+    rng = np.random.default_rng(7)
+    cases = [("A", dict(fmin=10, maxdepth=9, pmin=2, emax=2.0)), ("", dict(fmin=10, maxdepth=6, pmin=1, emax=0.0)),
+             ("".join(rng.choice(list("ACGT"), 7)), dict(fmin=10, pmin=2, emax=2.0)),
+             ("".join(rng.choice(list("ACGT"), 7)), dict(fmin=3, pmin=1, pmax=2, emax=1.5, emin=0.2, mindepth=12))]
+    for p, kw in cases:
+        got, st = pydsm.mine(idx, p, **kw)
+        want, ost = orc.mine(oidx, names, [p], threads=4, **kw)
+        assert got == want, (p, kw)
+        assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (p, kw)
+    for ix in idx + oidx:
+        ix.close()
