@@ -40,7 +40,9 @@ int main(int argc, char** argv) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        if (bb == 128) hipLaunchKernelGGL(gather_kernel<128>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, tab, bytes / 128, nq, out);
+        if (bb == 32) hipLaunchKernelGGL(gather_kernel<32>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, tab, bytes / 32, nq, out);
+        else if (bb == 16) hipLaunchKernelGGL(gather_kernel<16>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, tab, bytes / 16, nq, out);
+        else if (bb == 128) hipLaunchKernelGGL(gather_kernel<128>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, tab, bytes / 128, nq, out);
         else hipLaunchKernelGGL(gather_kernel<64>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, tab, bytes / 64, nq, out);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
