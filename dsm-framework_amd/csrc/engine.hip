@@ -1044,6 +1044,110 @@ struct Emitter {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// A sample given as an already enumerated trie: the byte stream an (unmodified reference) client sent to the server.
+// Parsed on the host with TrieReader's token rules (TrieReader.h:32-106: '(' sym ... varint(freq) ['R' varint(count)]
+// leftchar ')', checksum R for depth <= 6) into level arrays, in the order the nodes appear = path order inside a level.
+// ---------------------------------------------------------------------------------------------
+}  // namespace dsm
+struct dsm_trie {
+    int device = 0;
+    dsm::u64 nodes = 0, maxfreq = 0;
+    std::vector<dsm::u64> level_off;  // level l holds nodes [level_off[l], level_off[l+1]); level 0 = the root
+    dsm::u64* d_freq = nullptr;       // per node
+    dsm::u8* d_pl = nullptr;          // bits 0-3 children present, bits 4-6 left-char code
+    dsm::u32* d_fc = nullptr;         // index of the first child inside the next level
+};
+namespace dsm {
+
+struct HostTrieLevel {
+    std::vector<u64> freq;
+    std::vector<u8> pl;
+    std::vector<u32> fc;
+};
+
+static int parse_client_stream(const u8* p, size_t n, std::vector<HostTrieLevel>& L, u64* nodes, u64* maxfreq) {
+    L.clear();
+    L.emplace_back();
+    L[0].freq.push_back(0); L[0].pl.push_back(0); L[0].fc.push_back(0);
+    std::vector<u32> stack;  // index of the open node at every depth (stack[0] = root)
+    stack.push_back(0);
+    size_t pos = 0;
+    u64 opened = 0, mf = 0;
+    auto varint = [&](u64& v) -> bool {  // ServerSocket.h:45-58
+        if (pos >= n) return false;
+        u8 c = p[pos++];
+        if (c >= 0x80) { v = (u64)(c ^ 0x80); return true; }
+        if (c > 8 || pos + c > n) return false;
+        v = 0;
+        for (u8 i = 0; i < c; ++i) v |= (u64)p[pos++] << (8 * i);
+        return true;
+    };
+    while (pos < n) {
+        const size_t depth = stack.size() - 1;
+        if (p[pos] == '(') {
+            if (pos + 1 >= n) return fail(DSM_E_FORMAT, "stream: truncated child");
+            const u8 sym = p[pos + 1];
+            const int k = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : sym == 'T' ? 3 : -1;
+            if (k < 0) return fail(DSM_E_FORMAT, "stream: expecting dna byte");  // TrieReader.h:58-63
+            pos += 2;
+            if (L.size() <= depth + 1) L.emplace_back();
+            HostTrieLevel& me = L[depth + 1];
+            HostTrieLevel& par = L[depth];
+            const u32 pi = stack.back();
+            if ((par.pl[pi] & 15) == 0) par.fc[pi] = (u32)me.freq.size();
+            if ((par.pl[pi] & 15u) >> k) return fail(DSM_E_FORMAT, "stream: children out of order");  // A < C < G < T, each once
+            par.pl[pi] |= (u8)(1u << k);
+            me.freq.push_back(0); me.pl.push_back(0); me.fc.push_back(0);
+            if (me.freq.size() > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "stream: level too wide");
+            stack.push_back((u32)(me.freq.size() - 1));
+            ++opened;
+        } else {
+            if (depth == 0) return fail(DSM_E_FORMAT, "stream: unexpected byte at top level");
+            u64 f = 0;
+            if (!varint(f)) return fail(DSM_E_FORMAT, "stream: bad frequency");
+            if (depth <= 6) {  // TrieReader.h:84-106
+                if (pos >= n || p[pos] != 'R') return fail(DSM_E_FORMAT, "stream: expecting R byte");
+                ++pos;
+                u64 chk = 0;
+                if (!varint(chk)) return fail(DSM_E_FORMAT, "stream: bad checksum");
+                if (chk != opened) return fail(DSM_E_FORMAT, "stream: checksum mismatch");
+            }
+            if (pos + 2 > n) return fail(DSM_E_FORMAT, "stream: truncated close");
+            const u8 lc = p[pos], cl = p[pos + 1];
+            pos += 2;
+            if (cl != ')') return fail(DSM_E_FORMAT, "stream: expecting ) byte");  // TrieReader.h:75-81
+            const int code = lc == '0' ? 0 : lc == 'A' ? 1 : lc == 'C' ? 2 : lc == 'G' ? 3 : lc == 'T' ? 4 : lc == 'N' ? 5 : -1;
+            if (code < 0) return fail(DSM_E_FORMAT, "stream: bad left char");
+            HostTrieLevel& me = L[depth];
+            const u32 mi = stack.back();
+            me.freq[mi] = f;
+            me.pl[mi] |= (u8)(code << 4);
+            mf = f > mf ? f : mf;
+            stack.pop_back();
+        }
+    }
+    if (stack.size() != 1) return fail(DSM_E_FORMAT, "stream: unbalanced parentheses");
+    *nodes = opened;
+    *maxfreq = mf;
+    return 0;
+}
+
+template <typename P>
+__global__ void trie_expand_kernel(u32 F, const u32* __restrict__ rp, const u64* __restrict__ freq, const u8* __restrict__ plv,
+                                   const u32* __restrict__ fc, P* __restrict__ valf, u8* __restrict__ pl, u32* __restrict__ tpos,
+                                   u32 allowed) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const u32 r = rp[i];
+    if (r == DEAD) { valf[i] = 0; pl[i] = 0; return; }
+    const u32 full = plv[r];
+    valf[i] = (P)freq[r];
+    pl[i] = (u8)((full & 0xF0u) | (full & allowed & 15u));  // allowed: 15, one enforced child, or 0 (see ExpandArgs)
+    const u32 low = allowed & (0u - allowed);
+    tpos[i] = fc[r] + __popc(full & 15u & (low - 1));       // children before the first allowed one keep their slots
+}
+
 // emission-side allocations (candidates, tuple assembly) come from their own arena in multi-rank runs, so that the structure
 // arena is used identically on every rank and only the emission side can differ (owner-only emission)
 #define EARENA_GET(var, T, n)                                                                       \
@@ -1056,6 +1160,8 @@ template <typename P>
 class Engine {
   public:
     std::vector<const dsm_index*> idx;
+    std::vector<const dsm_trie*> tries;  // trie mode: samples are parsed client streams instead of indexes
+    bool trie_mode = false;
     dsm_params prm;
     bool stream_mode = false;
     int nlocal = 0, world = 1, rank = 0;
@@ -1116,6 +1222,30 @@ class Engine {
     }
 
     int init(dsm_index* const* ix, int n, const dsm_params& p, bool stream) {
+        device = ix[0]->device;
+        u64 nsum = 0, nmax = 0;
+        for (int k = 0; k < n; ++k) {
+            if (ix[k]->device != device) return fail(DSM_E_INVAL, "all local indexes must live on one device");
+            idx.push_back(ix[k]);
+            nsum += ix[k]->meta.n;
+            nmax = ix[k]->meta.n > nmax ? ix[k]->meta.n : nmax;
+        }
+        return init_common(n, p, stream, nsum, nmax);
+    }
+    int init_tries(dsm_trie* const* tr, int n, const dsm_params& p) {
+        device = tr[0]->device;
+        trie_mode = true;
+        u64 nsum = 0, nmax = 0;
+        for (int k = 0; k < n; ++k) {
+            if (tr[k]->device != device) return fail(DSM_E_INVAL, "all tries must live on one device");
+            tries.push_back(tr[k]);
+            nsum += tr[k]->nodes + 16;
+            nmax = tr[k]->nodes + 16 > nmax ? tr[k]->nodes + 16 : nmax;
+        }
+        return init_common(n, p, false, nsum, nmax);
+    }
+    // nsum / nmax: total and largest sample size (indexed symbols, or trie nodes): bounds of a frontier level
+    int init_common(int n, const dsm_params& p, bool stream, u64 nsum, u64 nmax) {
         memset(&stats, 0, sizeof stats);
         prm = p;
         stream_mode = stream;
@@ -1124,22 +1254,15 @@ class Engine {
         rank = world > 1 ? (int)p.rank : 0;
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
-        if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 32 local indexes per process");
+        if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 32 local samples per process");
         d = (u32)(world * nlocal);
         if (d > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
         st = (hipStream_t)p.stream;
-        device = ix[0]->device;
-        for (int k = 0; k < n; ++k) {
-            if (ix[k]->device != device) return fail(DSM_E_INVAL, "all local indexes must live on one device");
-            idx.push_back(ix[k]);
-        }
         DSM_HIP(hipSetDevice(device));
         size_t free_b = 0, total_b = 0;
         DSM_HIP(hipMemGetInfo(&free_b, &total_b));
         // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
         // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
-        u64 nsum = 0, nmax = 0;
-        for (int k = 0; k < n; ++k) { nsum += ix[k]->meta.n; nmax = ix[k]->meta.n > nmax ? ix[k]->meta.n : nmax; }
         const u64 fbound = (world > 1 ? (u64)d * nmax : nsum) + 16;
         u64 budget = p.arena_bytes ? p.arena_bytes : (u64)(free_b * 0.7);
         if (!p.arena_bytes) {
@@ -1193,7 +1316,7 @@ class Engine {
         const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
         if (int rc = dalloc(adv_sums, nadv)) return rc;
         if (int rc = dalloc(blockcnt, (size_t)Fcap / 256 + 8)) return rc;
-        if (d > 1) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
+        if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
@@ -1302,7 +1425,12 @@ class Engine {
 
         // ---- level 0: the root (EnumerateQuery::enumerate, EnumerateQuery.cpp:9-37) --------------
         const char* bases = "ACGT";
-        for (int s = 0; s < nlocal; ++s) {
+        for (int s = 0; s < nlocal && trie_mode; ++s) {  // the root of a parsed stream is its node 0
+            const u32 zero = 0;
+            DSM_HIP(hipMemcpyAsync(rp[0][s], &zero, sizeof(u32), hipMemcpyHostToDevice, st));
+            stats.reported += tries[s]->nodes;
+        }
+        for (int s = 0; s < nlocal && !trie_mode; ++s) {
             const IndexMeta& m = idx[s]->meta;
             P h[REC_FIELDS];
             h[0] = 0;
@@ -1374,14 +1502,26 @@ class Engine {
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             DSM_HIP(hipEventRecord(ea0, st));
-            for (int s = 0; s < nlocal; ++s) {
+            for (int s = 0; s < nlocal && trie_mode; ++s) {  // children, frequency and left char come from the parsed stream
+                const dsm_trie* t = tries[s];
+                P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);
+                u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;
+                if (depth + 1 < t->level_off.size()) {
+                    const u64 o = t->level_off[depth];
+                    hipLaunchKernelGGL((trie_expand_kernel<P>), grid_for(F), dim3(256), 0, st, F, rp[cur][s], t->d_freq + o, t->d_pl + o, t->d_fc + o, cf, cl, tpos[s], ea.allowed);
+                } else {  // deeper than this sample's trie: it holds none of these nodes
+                    DSM_HIP(hipMemsetAsync(cf, 0, (size_t)F * fb, st));
+                    DSM_HIP(hipMemsetAsync(cl, 0, (size_t)F, st));
+                }
+            }
+            for (int s = 0; s < nlocal && !trie_mode; ++s) {
                 const IndexMeta& m = idx[s]->meta;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
                 P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);                  // this sample's frequency column
                 u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;                  // children nibble | left char << 4
                 hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
-                                   tpos[s], cf, cl, ea, d_counters, d == 1 ? blockcnt : (u32*)nullptr, d_childmax);
+                                   tpos[s], cf, cl, ea, d_counters, (d == 1 && !trie_mode) ? blockcnt : (u32*)nullptr, d_childmax);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
@@ -1417,8 +1557,8 @@ class Engine {
             if (nb == 1) {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
             } else {
-                ao.sinfo = d > 1 ? sinfo : nullptr;
-                if (d == 1)
+                ao.sinfo = (d > 1 || trie_mode) ? sinfo : nullptr;
+                if (d == 1 && !trie_mode)
                     hipLaunchKernelGGL(pair_sum_kernel, grid_for(nb), dim3(256), 0, st, blockcnt, (u32)((F + 255) / 256), adv_sums, nb);
                 else
                     hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums, sinfo);
@@ -1433,7 +1573,7 @@ class Engine {
             {
                 u64 mx = 0;
                 for (int r = 0; r < world; ++r) mx = h_childmax[r] > mx ? h_childmax[r] : mx;
-                w16 = mx < 65535;  // the next level's frequencies all fit 16 bits
+                w16 = mx < 65535 && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
             }
             for (int s = 0; s < nlocal; ++s)
                 if (h_totals[8 + s] > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
@@ -1843,6 +1983,13 @@ static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 max
     return rc;
 }
 
+template <typename P>
+static int merge_impl(dsm_trie* const* tr, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    std::unique_ptr<MinerT<P>> m(new MinerT<P>());
+    int rc = m->e.init_tries(tr, n, *p);
+    if (rc) return rc;
+    return m->run("", sink, nullptr, ctx, stats);
+}
 }  // namespace dsm
 
 using namespace dsm;
@@ -1905,6 +2052,61 @@ int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, 
     return reinterpret_cast<MinerBase*>(m)->run_many(prefixes, nprefix, sink, nullptr, ctx, stats);
 }
 void dsm_miner_destroy(dsm_miner* m) { delete reinterpret_cast<MinerBase*>(m); }
+
+int dsm_trie_parse(const uint8_t* bytes, size_t n, int device, dsm_trie** out) {
+    if ((!bytes && n) || !out) return fail(DSM_E_INVAL, "dsm_trie_parse: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSM_E_NODEV, "dsm_trie_parse: no HIP device");
+    if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_trie_parse: bad device ordinal");
+    std::vector<HostTrieLevel> L;
+    u64 nodes = 0, mf = 0;
+    if (int rc = parse_client_stream(bytes, n, L, &nodes, &mf)) return rc;
+    std::unique_ptr<dsm_trie> t(new dsm_trie());
+    t->device = device;
+    t->nodes = nodes;
+    t->maxfreq = mf;
+    u64 tot = 0;
+    for (auto& l : L) { t->level_off.push_back(tot); tot += l.freq.size(); }
+    t->level_off.push_back(tot);
+    DSM_HIP(hipSetDevice(device));
+    DSM_HIP(hipMalloc((void**)&t->d_freq, tot * sizeof(u64)));
+    DSM_HIP(hipMalloc((void**)&t->d_pl, tot));
+    DSM_HIP(hipMalloc((void**)&t->d_fc, tot * sizeof(u32)));
+    for (size_t l = 0; l < L.size(); ++l) {
+        const u64 o = t->level_off[l], k = L[l].freq.size();
+        DSM_HIP(hipMemcpy(t->d_freq + o, L[l].freq.data(), k * sizeof(u64), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_pl + o, L[l].pl.data(), k, hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_fc + o, L[l].fc.data(), k * sizeof(u32), hipMemcpyHostToDevice));
+    }
+    *out = t.release();
+    return DSM_OK;
+}
+void dsm_trie_free(dsm_trie* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->d_freq) (void)hipFree(t->d_freq);
+    if (t->d_pl) (void)hipFree(t->d_pl);
+    if (t->d_fc) (void)hipFree(t->d_fc);
+    delete t;
+}
+uint64_t dsm_trie_nodes(const dsm_trie* t) { return t ? t->nodes : 0; }
+
+int dsm_merge(dsm_trie* const* tries, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
+    if (!tries || n <= 0 || !p) return fail(DSM_E_INVAL, "dsm_merge: bad arguments");
+    bool wide = p->wide != 0;
+    for (int k = 0; k < n; ++k) {
+        if (!tries[k]) return fail(DSM_E_INVAL, "dsm_merge: null trie");
+        if (tries[k]->maxfreq >= 0xFFFFFFF0ull) wide = true;
+    }
+    dsm_params q = *p;
+    q.world_size = 1;  // one process holds every stream, like one metaserver
+    q.rank = 0;
+    q.fmin = 0;        // the clients already applied --fmin / --maxdepth
+    q.maxdepth = ~0u;
+    if (wide) return merge_impl<u64>(tries, n, &q, sink, ctx, stats);
+    return merge_impl<u32>(tries, n, &q, sink, ctx, stats);
+}
 
 int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // metaserver.cpp:472-484
     if (!b || !text || !len) return fail(DSM_E_INVAL, "dsm_format_batch: null argument");

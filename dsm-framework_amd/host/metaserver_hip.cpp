@@ -1,0 +1,135 @@
+// metaserver_hip -- drop-in for the reference server (metaserver.cpp:488-815): same options, the expected sample names
+// on stdin, one TCP connection per sample carrying the reference wire protocol, reference-format tuples on stdout.
+// Unmodified reference clients (metaenumerate) can feed it.  Streams are received completely, checked with the
+// reference's token rules (dsm_trie_parse) and merged on the GPU (dsm_merge).
+//   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] < names.txt
+#include <getopt.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dsmhip.h"
+
+static int print_batch(void*, const dsm_tuple_batch* b) {  // metaserver.cpp:472-484
+    char* text = nullptr;
+    size_t len = 0;
+    if (dsm_format_batch(b, &text, &len)) return 1;
+    size_t w = fwrite(text, 1, len, stdout);
+    dsm_free(text);
+    return w != len;
+}
+
+int main(int argc, char** argv) {
+    if (argc <= 1) { std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1; }
+    dsm_params p;
+    dsm_params_default(&p);
+    int port = 54666, device = 0;  // metaserver.cpp:515
+    bool verbose = false;
+    static option long_options[] = {{"pmin", required_argument, 0, 'P'},     {"pmax", required_argument, 0, 258},
+                                    {"port", required_argument, 0, 'p'},     {"mindepth", required_argument, 0, 'm'},
+                                    {"emin", required_argument, 0, 'e'},     {"emax", required_argument, 0, 'E'},
+                                    {"verbose", no_argument, 0, 'v'},        {"debug", no_argument, 0, 256},
+                                    {"device", required_argument, 0, 257},   {0, 0, 0, 0}};
+    int c, oi = 0;
+    while ((c = getopt_long(argc, argv, "P:p:m:e:E:F:T:vA", long_options, &oi)) != -1) {
+        switch (c) {
+            case 'P': p.pmin = (unsigned)atoi(optarg); break;
+            case 258: p.pmax = (unsigned)atoi(optarg); break;
+            case 'p': port = atoi(optarg); if (port < 1024) { std::cerr << argv[0] << ": argument of -p, --port must be >= 1024" << std::endl; return 1; } break;
+            case 'm': p.mindepth = (unsigned)atoi(optarg); break;
+            case 'e': p.emin = atof(optarg); break;
+            case 'E': p.emax = atof(optarg); break;
+            case 'v': verbose = true; break;
+            case 256: case 'F': case 'T': case 'A': break;  // progress options of the reference: accepted, no effect
+            case 257: device = atoi(optarg); break;
+            default: std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1;
+        }
+    }
+    if (p.emax < 0) { std::cerr << argv[0] << ": error: expecting parameter --emax" << std::endl; return 1; }  // metaserver.cpp:582-586
+    if (p.emin > p.emax) { std::cerr << argv[0] << ": error: -e <double> must be smaller than or equal to -E <double>" << std::endl; return 1; }
+
+    std::map<std::string, int> libtoid;  // metaserver.cpp:606-653
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        if (line.empty()) continue;
+        std::string name = line.substr(0, line.find_first_of('\t'));
+        if (libtoid.count(name)) { std::cerr << "DUPLICATE CLIENT NAME IN stdin! name = " << name << std::endl; return 1; }
+        int id = (int)libtoid.size();
+        libtoid[name] = id;
+    }
+    const size_t d = libtoid.size();
+    if (d == 0) { std::cerr << "no expected inputs" << std::endl; return 1; }
+    if (d > 273) { std::cerr << "Too many input readers requested! MAX_READERS was 273" << std::endl; return 1; }
+
+    int sock = socket(AF_INET, SOCK_STREAM, 0);  // ServerSocket::init, ServerSocket.cpp:13-48
+    int yes = 1;
+    setsockopt(sock, SOL_SOCKET, SO_REUSEADDR, &yes, sizeof yes);
+    sockaddr_in addr;
+    memset(&addr, 0, sizeof addr);
+    addr.sin_family = AF_INET;
+    addr.sin_addr.s_addr = INADDR_ANY;
+    addr.sin_port = htons(port);
+    if (bind(sock, (sockaddr*)&addr, sizeof addr) < 0 || listen(sock, 256) < 0) { std::cerr << "ERROR on binding" << std::endl; return 1; }
+
+    std::vector<std::vector<uint8_t>> streams(d);
+    std::vector<bool> seen(d, false);
+    std::vector<std::thread> readers;
+    size_t pending = d;
+    while (pending) {  // metaserver.cpp:682-728: handshake 'S' name '.', then the node stream until EOF
+        int fd = accept(sock, nullptr, nullptr);
+        if (fd < 0) { std::cerr << "ERROR on accept" << std::endl; return 1; }
+        uint8_t ch = 0;
+        if (recv(fd, &ch, 1, MSG_WAITALL) != 1 || ch != 'S') { std::cerr << "received invalid start byte: " << (int)ch << std::endl; return 1; }
+        std::string name;
+        for (;;) {
+            if (recv(fd, &ch, 1, MSG_WAITALL) != 1) { std::cerr << "connection closed inside the handshake" << std::endl; return 1; }
+            if (ch == '.') break;
+            name += (char)ch;
+        }
+        auto f = libtoid.find(name);
+        if (f == libtoid.end()) { std::cerr << "received invalid libname: \"" << name << "\"" << std::endl; return 1; }
+        const int id = f->second;
+        if (seen[id]) { std::cerr << "DUPLICATE CONNECTING CLIENT! id = " << id << ", name = " << name << std::endl; return 1; }
+        seen[id] = true;
+        --pending;
+        if (verbose) std::cerr << "new connection id = " << id << ", name = " << name << " (" << pending << " pending)" << std::endl;
+        readers.emplace_back([fd, id, &streams] {
+            std::vector<uint8_t>& s = streams[id];
+            std::vector<uint8_t> buf(1 << 20);
+            for (;;) {
+                ssize_t r = recv(fd, buf.data(), buf.size(), 0);
+                if (r <= 0) break;
+                s.insert(s.end(), buf.begin(), buf.begin() + r);
+            }
+            close(fd);
+        });
+    }
+    for (auto& t : readers) t.join();
+    close(sock);
+
+    std::vector<dsm_trie*> tries(d, nullptr);
+    for (size_t k = 0; k < d; ++k) {
+        if (dsm_trie_parse(streams[k].data(), streams[k].size(), device, &tries[k])) {
+            std::cerr << "error: " << dsm_last_error() << " (reader " << k << ")" << std::endl;
+            return 1;
+        }
+        std::vector<uint8_t>().swap(streams[k]);
+    }
+    dsm_stats st;
+    if (dsm_merge(tries.data(), (int)d, &p, print_batch, nullptr, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+    fflush(stdout);
+    if (verbose)
+        std::cerr << "Number of paths: " << st.union_nodes << std::endl << "Number of reported paths: " << st.tuples << std::endl
+                  << "Number of reported occs: " << st.pairs << std::endl;
+    for (auto* t : tries) dsm_trie_free(t);
+    return 0;
+}

@@ -101,6 +101,11 @@ def lib():
         L.dsm_miner_mine_many.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_enumerate.argtypes = [C.c_void_p, C.c_char_p, BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_destroy.argtypes = [C.c_void_p]
+        L.dsm_trie_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_trie_free.argtypes = [C.c_void_p]
+        L.dsm_trie_nodes.restype = C.c_uint64
+        L.dsm_trie_nodes.argtypes = [C.c_void_p]
+        L.dsm_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.dsm_free.argtypes = [C.c_void_p]
         _lib = L
@@ -311,4 +316,37 @@ def mine(indexes, prefix, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, minde
     hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
     st = Stats()
     _check(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)))
+    return (b"".join(out) if text else None), st
+
+
+class Trie:
+    """One client connection's byte stream (what a reference metaenumerate sends), checked and uploaded (TrieReader.h:32-106).
+    `stream` may include the b'S' name b'.' handshake; the sample name is then available as .name."""
+
+    def __init__(self, stream, device=0):
+        self.name = None
+        body = stream
+        if stream[:1] == b"S" and b"." in stream:
+            dot = stream.index(b".")
+            self.name = stream[1:dot].decode(errors="replace")
+            body = stream[dot + 1:]
+        self.h = C.c_void_p()
+        _check(lib().dsm_trie_parse(body, len(body), device, C.byref(self.h)))
+        self.nodes = lib().dsm_trie_nodes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().dsm_trie_free(self.h)
+            self.h = C.c_void_p()
+
+
+def merge(tries, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0, text=True, on_batch=None):
+    """metaserver's traverse() over parsed client streams; tries[k] is sample id k.  -> (tuple text, Stats)"""
+    keep = []
+    p = _make_params(0, MAXDEPTH_NONE, pmin, pmax, mindepth, emin, emax, 1, 0, None, None, arena_bytes, 0, None, keep)
+    out = []
+    cb = _tuple_sink(out, text, on_batch)
+    hs = (C.c_void_p * len(tries))(*[t.h for t in tries])
+    st = Stats()
+    _check(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)))
     return (b"".join(out) if text else None), st

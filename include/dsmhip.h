@@ -170,6 +170,19 @@ void dsm_params_default(dsm_params* p);
 
 int dsm_mine(dsm_index* const* idx, int nlocal, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------
+ * Server side of the wire protocol.  Replaces TrieReader (TrieReader.h:32-106) + metaserver's traverse() for streams
+ * that were produced elsewhere, e.g. by unmodified reference clients over TCP: dsm_trie_parse checks one connection's
+ * bytes (everything after the 'S' name '.' handshake) with the reference's token rules and R checksums and uploads
+ * the trie; dsm_merge merges d of them (sample id = position in the array) with the same kernels dsm_mine uses and
+ * delivers the tuples the reference server would print.  p->fmin / maxdepth / prefix / world_size are ignored.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsm_trie dsm_trie;
+int dsm_trie_parse(const uint8_t* bytes, size_t n, int device, dsm_trie** out);
+void dsm_trie_free(dsm_trie* t);
+uint64_t dsm_trie_nodes(const dsm_trie* t);
+int dsm_merge(dsm_trie* const* tries, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
+
 /* Persistent form of the two calls above: device buffers are allocated once and reused for every
  * prefix (the reference keeps one EnumerateQuery + socket per prefix alive for the whole run,
  * metaenumerate.cpp:268-309).  p->prefix is ignored at creation; fmin/maxdepth/pmin/... are fixed.
