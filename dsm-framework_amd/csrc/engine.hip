@@ -339,7 +339,7 @@ __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
 // ---------------------------------------------------------------------------------------------
 // advance: union frontier of the next level.  A thread owns 8 consecutive slots = 2 parents.
 // ---------------------------------------------------------------------------------------------
-constexpr int MAX_LOCAL = 32;  // local indexes per process
+constexpr int MAX_LOCAL = 273;  // local samples per process (MAX_READERS, metaserver.cpp:19)
 constexpr int ADV_SLOTS = 8;
 constexpr int ADV_TILE = 256 * ADV_SLOTS;
 
@@ -394,8 +394,8 @@ struct AdvanceOut {
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
     // per local sample record handles
-    u32* rp[MAX_LOCAL];
-    const u32* tpos[MAX_LOCAL];
+    u32* const* rp;          // device tables of nlocal pointers
+    const u32* const* tpos;
     u32 nlocal, rank;
     const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
 };
@@ -1174,6 +1174,8 @@ class Engine {
     std::vector<P*> rec[2];     // compact child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
     std::vector<u32*> tpos;     // handle of the first child record of every node of the level being expanded
+    u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*] and tpos[*] for the advance kernel
+    u32** d_tpos_tab = nullptr;
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
@@ -1188,7 +1190,7 @@ class Engine {
     u32* d_alloc = nullptr;   // [nlocal] compact-record allocation counters
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
-    u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, then u64 totals
+    u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, [8..8+MAX_LOCAL) record allocations, [300..] u64 totals
     u64* h_childmax = nullptr;  // pinned: one per rank
     std::vector<void*> owned;
     Arena arena;
@@ -1254,7 +1256,7 @@ class Engine {
         rank = world > 1 ? (int)p.rank : 0;
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
-        if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 32 local samples per process");
+        if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 273 local samples per process");
         d = (u32)(world * nlocal);
         if (d > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
         st = (hipStream_t)p.stream;
@@ -1313,6 +1315,12 @@ class Engine {
             if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
             rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp);
         }
+        for (int k = 0; k < 2; ++k) {
+            if (int rc = dalloc(d_rp_tab[k], (size_t)nlocal)) return rc;
+            DSM_HIP(hipMemcpy(d_rp_tab[k], rp[k].data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
+        }
+        if (int rc = dalloc(d_tpos_tab, (size_t)nlocal)) return rc;
+        DSM_HIP(hipMemcpy(d_tpos_tab, tpos.data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
         const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
         if (int rc = dalloc(adv_sums, nadv)) return rc;
         if (int rc = dalloc(blockcnt, (size_t)Fcap / 256 + 8)) return rc;
@@ -1333,7 +1341,7 @@ class Engine {
         if (int rc = dalloc(d_alloc, MAX_LOCAL)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
-        DSM_HIP(hipHostMalloc((void**)&h_totals, 64 * sizeof(u32)));
+        DSM_HIP(hipHostMalloc((void**)&h_totals, 320 * sizeof(u32)));
         DSM_HIP(hipHostMalloc((void**)&h_childmax, (size_t)(world > 0 ? world : 1) * sizeof(u64)));
         size_t used = 0;
         {
@@ -1553,7 +1561,8 @@ class Engine {
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
-            for (int s = 0; s < nlocal; ++s) { ao.rp[s] = rp[nxt][s]; ao.tpos[s] = tpos[s]; }
+            ao.rp = d_rp_tab[nxt];
+            ao.tpos = d_tpos_tab;
             if (nb == 1) {
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
             } else {
@@ -1700,14 +1709,14 @@ class Engine {
         u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         if (one) {
             exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
-            DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipMemcpyAsync(h_totals + 300, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
         } else {
             exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-            DSM_HIP(hipMemcpyAsync(h_totals + 48, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+            DSM_HIP(hipMemcpyAsync(h_totals + 300, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
         }
         DSM_HIP(hipStreamSynchronize(st));
         u64 tot = 0;
-        memcpy(&tot, h_totals + 48, sizeof tot);
+        memcpy(&tot, h_totals + 300, sizeof tot);
         me.ncand = (u32)(tot & 0xFFFFFFFFu);
         me.npairs = one ? me.ncand : (u32)(tot >> 32);
         if (me.ncand) {
