@@ -1279,8 +1279,8 @@ class Engine {
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
         u64 fc = budget / 3 / perF;
         if (fc > (1u << 28)) fc = 1u << 28;
-        if (fc > fbound) fc = fbound;
         if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
+        if (fc > fbound) fc = fbound < 1024 ? 1024 : fbound;
         Fcap = (u32)fc;
         bpr_cap = (((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull) + 16;
         if (p.exchange_send && p.exchange_recv && world > 1) {

@@ -242,3 +242,71 @@ def test_thirty_samples_exact_pair_order(golden, pydsm_mod):
             assert st.pair_order_exact == 1
     for ix in idx:
         ix.close()
+
+
+def _downgrade_fmi(raw, ver):
+    """Rewrite a v17 .fmi as v16 / v15 / v14 (FMIndex.cpp:267-290, HuffWT.h:21-37): v<16 stores code counts as u32, v14 stores C[] as u32."""
+    import struct
+    pos = 1
+    n, sr = struct.unpack_from("<QI", raw, pos)
+    pos += 12
+    C = struct.unpack_from("<256Q", raw, pos)
+    pos += 2048
+    (bwt_end,) = struct.unpack_from("<Q", raw, pos)
+    pos += 8
+    codes = [struct.unpack_from("<QII", raw, pos + 16 * i) for i in range(256)]
+    pos += 16 * 256
+    out = bytes([ver]) + struct.pack("<QI", n, sr)
+    out += struct.pack("<256I", *C) if ver == 14 else struct.pack("<256Q", *C)
+    out += struct.pack("<Q", bwt_end)
+    for cnt, bits, code in codes:
+        out += struct.pack("<III", cnt, bits, code) if ver < 16 else struct.pack("<QII", cnt, bits, code)
+    return out + raw[pos:]
+
+
+def test_older_fmi_versions_and_degenerate_alphabets(golden, pydsm_mod, tmp_path):
+    raw = golden.read("toy3/toy-2.fasta.fmi.gz")
+    ref = pydsm_mod.Index(golden.fmi("toy3", "toy-2"))
+    want, _ = ref.enumerate("GT", fmin=2)
+    for ver in (16, 15, 14):
+        p = tmp_path / ("v%d.toy-2.fasta.fmi" % ver)
+        p.write_bytes(_downgrade_fmi(raw, ver))
+        o = orc.Index(str(p))
+        with pydsm_mod.Index(str(p)) as g:
+            assert g.n == ref.n == o.n
+            got, _ = g.enumerate("GT", fmin=2)
+            assert got[got.index(b"."):] == want[want.index(b"."):]     # same node stream (the sample name differs)
+            assert got == o.enumerate(g.name, "GT", fmin=2)[0]
+        o.close()
+    ref.close()
+    # reads without any A,C,G,T: nothing to enumerate, LF still answers for the symbols that exist
+    from pydsm import builder
+    p = tmp_path / "onlyN.fasta.fmi"
+    builder.build_from_fasta(">a\nNNNNNN\n>b\nNNN\n", str(p))
+    o = orc.Index(str(p))
+    with pydsm_mod.Index(str(p)) as g:
+        assert g.check() == g.n == o.n
+        for prefix in ("A", ""):
+            got, st = g.enumerate(prefix, fmin=1)
+            assert got == o.enumerate(g.name, prefix, fmin=1)[0] and st.reported == 0
+        pos = np.arange(g.n, dtype=np.uint64)
+        for c in (0, ord("-"), ord("N"), ord("A")):
+            assert (g.lf_batch(np.full(g.n, c, np.uint8), pos) == o.lf_batch(np.full(g.n, c, np.uint8), pos)).all()
+        text, _ = pydsm_mod.mine([g], "", fmin=1, pmin=1, emax=2.0)
+        assert text == b""
+    o.close()
+    # a single read: every node has frequency 1 or 2, deep unary chains (followOneBranch territory), depth == read length
+    p = tmp_path / "one.fasta.fmi"
+    builder.build_from_fasta(">a\nACGTTGCAACGGATTACAGATTACA\n", str(p))
+    o = orc.Index(str(p))
+    with pydsm_mod.Index(str(p)) as g:
+        for kw in (dict(fmin=1), dict(fmin=2), dict(fmin=1, maxdepth=7)):
+            for prefix in ("", "A", "GATTACA"):
+                got, st = g.enumerate(prefix, **kw)
+                want2, (rep, lf, ranks) = o.enumerate(g.name, prefix, **kw)
+                assert got == want2, (kw, prefix)
+                assert st.reported == rep
+        got, _ = pydsm_mod.mine([g], "", fmin=1, pmin=1, emax=0.0)
+        want3, _ = orc.mine([o], [g.name], [""], fmin=1, pmin=1, emax=0.0)
+        assert got == want3
+    o.close()
