@@ -36,8 +36,8 @@ __device__ __forceinline__ bool wt_bit(const u8* __restrict__ blob, const WtNode
 }
 
 // HuffWT::access, HuffWT.h:126-140 -> 3-bit code of BWT[i]
-__global__ void wt_decode_kernel(DevIndex ix, const int* __restrict__ byte2code, u8* __restrict__ codes) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void wt_decode_kernel(DevIndex ix, const int* __restrict__ byte2code, u8* __restrict__ codes, u64 base) {
+    u64 i = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ix.n) return;
     int t = 0;
     u64 p = i;
@@ -50,8 +50,8 @@ __global__ void wt_decode_kernel(DevIndex ix, const int* __restrict__ byte2code,
 }
 
 // one wave packs 64 symbols into three plane words with ballots
-__global__ __launch_bounds__(256) void pack_planes_kernel(const u8* __restrict__ codes, u64 n, u64 nblk, Blk* __restrict__ blk) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void pack_planes_kernel(const u8* __restrict__ codes, u64 n, u64 nblk, Blk* __restrict__ blk, u64 base) {
+    u64 i = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk * BLK_SYMS) return;  // grid is sized to whole blocks, so full waves reach the ballots
     u32 c = i < n ? codes[i] : 4u;     // padding past n is a non-base code: never counted
     u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
@@ -382,9 +382,17 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
     hipStream_t st = 0;
     {
         const int T = 256;
-        hipLaunchKernelGGL(wt_decode_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, dv, d_b2c.p, d_codes.p);
+        // a launch holds fewer than 2^32 threads: one thread per symbol goes out in slices of 2^31 (indexes beyond 2^32 symbols)
+        const u64 SLICE = 1ull << 31;
+        for (u64 base = 0; base < n; base += SLICE) {
+            const u64 m_ = n - base < SLICE ? n - base : SLICE;
+            hipLaunchKernelGGL(wt_decode_kernel, dim3((unsigned)((m_ + T - 1) / T)), dim3(T), 0, st, dv, d_b2c.p, d_codes.p, base);
+        }
         u64 padded = nblk * BLK_SYMS;
-        hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((padded + T - 1) / T)), dim3(T), 0, st, d_codes.p, n, nblk, d_blk.p);
+        for (u64 base = 0; base < padded; base += SLICE) {
+            const u64 m_ = padded - base < SLICE ? padded - base : SLICE;
+            hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((m_ + T - 1) / T)), dim3(T), 0, st, d_codes.p, n, nblk, d_blk.p, base);
+        }
         hipLaunchKernelGGL(block_hist_kernel, dim3((unsigned)((nblk + T - 1) / T)), dim3(T), 0, st, d_blk.p, nblk, d_cnt8.p);
         for (int c = 0; c < 8; ++c)
             exclusive_scan<u32, u64>(d_cnt8.p + (u64)c * nblk, d_pre8.p + (u64)c * nblk, nblk, d_tmp.p, (u64*)nullptr, st);
@@ -433,6 +441,7 @@ struct TmpDev {
 static int lf_dev(const dsm_index* idx, const u8* d_c, const u64* d_i, u64* d_out, size_t k, unsigned layout, hipStream_t st) {
     if (!idx || (k && (!d_c || !d_i || !d_out))) return fail(DSM_E_INVAL, "dsm_lf_batch: null argument");
     if (k == 0) return DSM_OK;
+    if (k >= (1ull << 32) - 256) return fail(DSM_E_INVAL, "dsm_lf_batch: at most 2^32 - 257 queries per call");
     DSM_HIP(hipSetDevice(idx->device));
     TmpDev tmp;
     LfTables* d_tb = tmp.get<LfTables>(1);

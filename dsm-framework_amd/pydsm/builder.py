@@ -236,8 +236,10 @@ def _bitrank_bytes(bits_t):
     integers = (n + 1 + 63) // 64
     pad = integers * 64 - n
     b = torch.cat([bits_t.to(torch.uint8), torch.zeros(pad, dtype=torch.uint8, device=bits_t.device)])
-    w8 = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=b.device)
-    by = (b.view(-1, 8).to(torch.int32) * w8).sum(1).to(torch.uint8)
+    b8 = b.view(-1, 8)
+    by = b8[:, 0].clone()
+    for k in range(1, 8):
+        by |= b8[:, k] << k                                      # bit k of a word is bit k%8 of byte k/8 (LSB first)
     wordpop = b.view(-1, 64).sum(1, dtype=torch.int64)           # popcount per 64-bit word
     del b
     cum = torch.cat([torch.zeros(1, dtype=torch.int64, device=wordpop.device), torch.cumsum(wordpop, 0)])
@@ -258,8 +260,12 @@ def _bitrank_bytes(bits_t):
 def _wt_node(seq, code_lut, level, out):
     """HuffWT::HuffWT(uchar*, n, codetable, level) + HuffWT::save (HuffWT.cpp:5-55,73-86), pre-order."""
     ch = int(seq[0])
-    bit = (code_lut[seq.long()] >> level) & 1
-    s = int(bit.sum())
+    lut = ((code_lut >> level) & 1).to(torch.uint8)
+    bit = torch.empty_like(seq)
+    step = 1 << 28                                 # bounded temporaries: indexes beyond 2^32 symbols are built this way too
+    for o in range(0, int(seq.numel()), step):
+        bit[o:o + step] = lut[seq[o:o + step].int()]
+    s = int(bit.sum(dtype=torch.int64))
     n = int(seq.numel())
     if s == 0 or s == n:
         out.append(struct.pack("<BB", 1, ch))
@@ -267,8 +273,9 @@ def _wt_node(seq, code_lut, level, out):
     out.append(struct.pack("<BB", 0, ch))
     out.extend(_bitrank_bytes(bit))
     m = bit.bool()
-    left = seq[~m]
-    right = seq[m]
+    step = 1 << 30
+    left = torch.cat([seq[o:o + step][~m[o:o + step]] for o in range(0, n, step)])
+    right = torch.cat([seq[o:o + step][m[o:o + step]] for o in range(0, n, step)])
     del bit, m
     _wt_node(left, code_lut, level + 1, out)
     del left

@@ -80,6 +80,9 @@ class Index:
         lib().orc_lf_batch(self.h, c.ctypes.data, i.ctypes.data, out.ctypes.data, len(c))
         return out
 
+    def getL(self, i):
+        return lib().orc_getL(self.h, i)
+
     def bwt(self):
         import numpy as np
         out = np.zeros(self.n, np.uint8)

@@ -123,3 +123,57 @@ def test_three_midsize_samples_against_oracle():
         assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (p, kw)
     for ix in idx + oidx:
         ix.close()
+
+
+def test_positions_beyond_2_32():
+    """configs[3]'s distinguishing feature is the position width (n = 8.08e9 > 2^32).  No BWT of that size can be sorted
+    here, but rank / LF / the enumeration are defined for ANY symbol string, so: a seeded pseudo-BWT of n = 2^32 + 3e8
+    symbols with DNA-like symbol frequencies is written as a v17 .fmi, and the device index (3 superblocks, 64-bit
+    positions, wide frequency columns) must answer exactly like the oracle on the same file."""
+    import torch
+    import orc
+    import pydsm
+    from pydsm import builder
+    n = int(os.environ.get("DSM_WIDE_N", str((1 << 32) + 300_000_000)))
+    d = os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "pseudo-%d.fmi" % n)
+    if not os.path.exists(path):
+        g = torch.Generator(device="cuda").manual_seed(4242)
+        syms = torch.tensor([0, ord("-"), ord("A"), ord("C"), ord("G"), ord("N"), ord("T")], dtype=torch.uint8, device="cuda")
+        cum = torch.tensor([0.005, 0.010, 0.258, 0.505, 0.750, 0.752], device="cuda")
+        bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+        step = 1 << 28
+        for o in range(0, n, step):
+            m = min(step, n - o)
+            bwt[o:o + m] = syms[torch.bucketize(torch.rand(m, device="cuda", generator=g), cum)]
+        builder.write_fmi(bwt, path + ".tmp", 1, 0)
+        del bwt
+        torch.cuda.empty_cache()
+        os.replace(path + ".tmp", path)
+    o = orc.Index(path)
+    with pydsm.Index(path) as ix:
+        assert ix.n == o.n == n
+        rng = np.random.default_rng(99)
+        Cc, cnt, bits, code = o.meta()
+        syms = [int(s) for s in np.nonzero(cnt)[0]]
+        edges = [0xFFFFFFFFFFFFFFFF, 0, n - 1]
+        for e in (1 << 31, 1 << 32, 2 << 31, 3 << 31):
+            edges += [x for x in (e - 129, e - 128, e - 2, e - 1, e, e + 1, e + 127, e + 128) if 0 <= x < n]
+        pos = np.concatenate([np.array(edges, np.uint64), rng.integers(0, n, 300000).astype(np.uint64)])
+        for s in syms:      # every symbol at every edge, then a random mix
+            cs = np.full(len(edges), s, np.uint8)
+            assert (ix.lf_batch(cs, pos[:len(edges)]) == o.lf_batch(cs, pos[:len(edges)])).all()
+        cs = rng.choice(syms, len(pos)).astype(np.uint8)
+        assert (ix.lf_batch(cs, pos) == o.lf_batch(cs, pos)).all()
+        assert (ix.getl_batch(pos[1:3000]) == np.array([o.getL(int(p)) for p in pos[1:3000]], np.uint8)).all()
+        with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m, pydsm.Miner([ix], fmin=10, stream_mode=True) as sm:
+            for p in ("ACGTAC", "TTTTTT", "GATTACA"):
+                got, st = m.mine(p)
+                want, ost = orc.mine([o], [ix.name], [p], fmin=10, pmin=1, emax=2.0)
+                assert got == want, p
+                assert st.reported > 1000 and (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples) == ost[:5], p
+                wire, sst = sm.enumerate(p)
+                owire, _ = o.enumerate(ix.name, p, fmin=10)
+                assert wire == owire, p
+    o.close()
