@@ -64,42 +64,45 @@ __device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4])
     out[3] = s3; out[2] = s1 - s3; out[1] = s0 - s3; out[0] = tot - s1 - s0 + s3;
 }
 
+// Superblock bases (C[c] + occurrences of c before the superblock).  An index below 2^31 symbols has one superblock:
+// its four bases travel as kernel arguments (scalar registers) instead of a dependent vector load per rank.
+struct SbArgs {
+    u64 sb0[4];
+    u32 one_sb;
+};
+
 // LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
 template <typename P>
-__device__ __forceinline__ void rank4(const DevIndex& ix, RankCache& rc, u64 x, P out[4], u32& lines) {
-    rc_select(ix, rc, x, lines);
-    u32 c4[4];
-    blk_counts4(rc.r, (u32)(x & (BLK_SYMS - 1)), c4);
-    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + rc.r.cnt[c] + c4[c]);
-}
-
-template <typename P>
-__device__ __forceinline__ void rank4_blk(const DevIndex& ix, const Blk16& r, u64 x, P out[4]) {
+__device__ __forceinline__ void rank4_blk(const DevIndex& ix, const SbArgs& sa, const Blk16& r, u64 x, P out[4]) {
     u32 c4[4];
     blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
-    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+    if (sa.one_sb) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + r.cnt[c] + c4[c]);
+        for (int c = 0; c < 4; ++c) out[c] = (P)(sa.sb0[c] + r.cnt[c] + c4[c]);
+    } else {
+        const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + r.cnt[c] + c4[c]);
+    }
 }
 
 // the same for the bases selected by `want` only (the children that survive): one masked popcount per base
 template <typename P>
-__device__ __forceinline__ void rank_sel(const DevIndex& ix, RankCache& rc, u64 x, u32 want, P out[4], u32& lines) {
+__device__ __forceinline__ void rank_sel(const DevIndex& ix, const SbArgs& sa, RankCache& rc, u64 x, u32 want, P out[4], u32& lines) {
     rc_select(ix, rc, x, lines);
     const Blk16& r = rc.r;
     const u32 off = (u32)(x & (BLK_SYMS - 1));
     u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
     u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
     u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
-    const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
+    const u64* sb = sa.one_sb ? sa.sb0 : ix.sbase + (x >> SB_SHIFT) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!((want >> c) & 1u)) continue;
         u64 xa = ba & ((c & 2) ? r.p1a : ~r.p1a) & ((c & 1) ? r.p0a : ~r.p0a);
         u64 xb = bb & ((c & 2) ? r.p1b : ~r.p1b) & ((c & 1) ? r.p0b : ~r.p0b);
-        out[c] = (P)(sb[c] + r.cnt[c] + (u32)(__popcll(xa) + __popcll(xb)));
+        const u64 base = sa.one_sb ? sa.sb0[c] : sb[c];
+        out[c] = (P)(base + r.cnt[c] + (u32)(__popcll(xa) + __popcll(xb)));
     }
 }
 
@@ -110,10 +113,14 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 }
 
 // record layout (struct of arrays): field f of record r lives at rec[f * cap + r]
-//   0 sp  1 ep  2..5 extmin[A,C,G,T]  6..9 extmax[A,C,G,T]     (EnumerateQuery.h:44-45, Query.h:110-111)
-// an empty ext has min = 1, max = 0.  Records are addressed through a handle per frontier node (rp[v]);
-// DEAD = the node is absent from this sample.
+//   0 sp  1 ep  2..5 min of the non-empty left-extension intervals  6..9 their max   (EnumerateQuery.h:44-45, Query.h:110-111)
+// followed by one byte per record: bit a set = the ext interval of base a (A,C,G,T) is non-empty.  Only the non-empty
+// intervals are stored, in base order, in the first popcount(mask) slots: most nodes have one, so the other slots are
+// neither written nor read.  Records are addressed through a handle per frontier node (rp[v]); DEAD = the node is
+// absent from this sample.
 constexpr int REC_FIELDS = 10;
+template <typename P>
+__host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
 constexpr u32 DEAD = 0xFFFFFFFFu;
 
@@ -124,6 +131,7 @@ struct ExpandArgs {
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
     u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
+    SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
 };
@@ -149,6 +157,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     u32 present = 0;  // bit c: child c is emitted
     u64 maxchild = 0; // largest frequency among the surviving children (decides the next level's column width)
     u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
+    u32 emask = 0;    // which left-extension intervals of this node are non-empty
     RankCache rc;
     rc.bi = ~0ull;
     rc.b1 = ~0ull;
@@ -160,27 +169,25 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         load_blk(ix.blk, rc.bi, rc.r);  // both ends of the interval are requested before anything waits
         ++lines;
         if (rc.b1 != rc.bi) { load_blk(ix.blk, rc.b1, rc.r1); ++lines; } else rc.b1 = ~0ull;
-        u32 ne = 0;
+        emask = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * a.cap)[r];
+        const u32 ne = __popc(emask);
         {
-            bool any = false, matches = false;
-            u32 lc = 0;
+            bool matches = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                emin[k] = rec[(size_t)(2 + k) * a.cap + r];
-                emax[k] = rec[(size_t)(6 + k) * a.cap + r];
-                if (emin[k] <= emax[k]) {
-                    ++ne;
-                    any = true; lc = k;
-                    if (emin[k] == sp && emax[k] == ep) matches = true;
+            for (int e = 0; e < 4; ++e) {
+                if ((u32)e < ne) {
+                    emin[e] = rec[(size_t)(2 + e) * a.cap + r];
+                    emax[e] = rec[(size_t)(6 + e) * a.cap + r];
+                    if (emin[e] == sp && emax[e] == ep) matches = true;
                 }
             }
-            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N'
-            mycode = matches ? 1u + lc : (any ? 5u : 0u);
+            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
+            mycode = matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u);
         }
-        rank4_blk<P>(ix, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
+        rank4_blk<P>(ix, a.sb, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
         const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-        if (rc.b1 != ~0ull) rank4_blk<P>(ix, rc.r1, (u64)ep + 1, Rep);  // LF(c, ep); r keeps the first block for the ext pass
-        else rank4_blk<P>(ix, rc.r, (u64)ep + 1, Rep);
+        if (rc.b1 != ~0ull) rank4_blk<P>(ix, a.sb, rc.r1, (u64)ep + 1, Rep);  // LF(c, ep); r keeps the first block for the ext pass
+        else rank4_blk<P>(ix, a.sb, rc.r, (u64)ep + 1, Rep);
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         if (single && a.allowed) n_rank += a.access_cost[lcode];
 #pragma unroll
@@ -246,30 +253,43 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     if (i < a.F) {
         if (present) {
             tpos[i] = pos;  // children of one parent get consecutive handles: child c is at tpos + #present children before c
-            // handle of every surviving child, interval fields first
-            u32 hnd[4];
-            {
-                u32 q = pos;
+        }
+        // Child records are written child-slot by child-slot (slot j = the j-th surviving base of the lane), not base by base:
+        // most nodes have one child, so a wave usually runs one pass over the ten fields instead of four, and the lanes of a
+        // pass write neighbouring handles.  cj[j] = base of slot j.
+        u32 cj[4];
+        {
+            u32 m = present;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    hnd[c] = q;
-                    if ((present >> c) & 1u) {
-                        if (q < a.cap) { out[q] = Rsp[c]; out[(size_t)a.cap + q] = Rep[c] - 1; }  // overflow is detected by the host from *alloc
-                        ++q;
-                    }
-                }
+            for (int j = 0; j < 4; ++j) { cj[j] = m ? (u32)__ffs(m) - 1u : 0u; m &= m - 1; }
+        }
+        const u32 kmax = (u32)__popcll(__ballot(k > 0)) ? (__any(k > 3) ? 4u : (__any(k > 2) ? 3u : (__any(k > 1) ? 2u : 1u))) : 0u;
+#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            if (j < kmax && j < k) {
+                const u32 c = cj[j], q = pos + j;
+                if (q < a.cap) { out[q] = DSM_PICK(Rsp, c); out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1; }  // overflow is detected by the host from *alloc
             }
+        }
+        if (present) {
             // left-extension intervals of the children (EnumerateQuery.cpp:44-55): LF at both ends of every non-empty
             // parent ext, only for the bases that survive.  Ends that coincide with sp / ep+1 or with the previous
-            // position (adjacent ext intervals share them) are not evaluated again.
+            // position (adjacent ext intervals share them) are not evaluated again.  A child keeps the intervals that stay
+            // non-empty, compacted into its first slots.
             u64 lastx = ~0ull;
             P lastv[4] = {0, 0, 0, 0};
+            u32 cm[4] = {0, 0, 0, 0};   // mask of child slot j
+            u32 cn[4] = {0, 0, 0, 0};   // its number of stored intervals
+            u32 mm = emask;
+            const u32 nemax = __any(mm & (mm - 1)) ? 4u : 1u;  // some lane holds more than one interval?
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bool nonempty_ext = emin[kk] <= emax[kk];
-                P lo[4], hi[4];
-                if (nonempty_ext) {
-                    const u64 xl = (u64)emin[kk], xh = (u64)emax[kk] + 1;
+            for (int e = 0; e < 4; ++e) {
+                if ((u32)e < nemax && mm) {
+                    const u32 kk = (u32)__ffs(mm) - 1u;
+                    mm &= mm - 1;
+                    P lo[4] = {1, 1, 1, 1}, hi[4] = {1, 1, 1, 1};
+                    const u64 xl = (u64)emin[e], xh = (u64)emax[e] + 1;
                     if (xl == (u64)sp) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lo[c] = Rsp[c];
@@ -277,27 +297,37 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lo[c] = lastv[c];
                     } else {
-                        rank_sel<P>(ix, rc, xl, present, lo, lines);
+                        rank_sel<P>(ix, a.sb, rc, xl, present, lo, lines);
                     }
                     if (xh == (u64)ep + 1) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) hi[c] = Rep[c];
                     } else {
-                        rank_sel<P>(ix, rc, xh, present, hi, lines);
+                        rank_sel<P>(ix, a.sb, rc, xh, present, hi, lines);
                         lastx = xh;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lastv[c] = hi[c];
                     }
-                }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!((present >> c) & 1u)) continue;
-                    P cmin = 1, cmax = 0;
-                    if (nonempty_ext && lo[c] <= hi[c] - 1) { cmin = lo[c]; cmax = hi[c] - 1; }
-                    if (hnd[c] < a.cap) { out[(size_t)(2 + kk) * a.cap + hnd[c]] = cmin; out[(size_t)(6 + kk) * a.cap + hnd[c]] = cmax; }
+                    for (u32 j = 0; j < 4; ++j) {
+                        if (j < kmax && j < k) {
+                            const u32 c = cj[j], q = pos + j;
+                            const P l = DSM_PICK(lo, c), h = DSM_PICK(hi, c);
+                            if (l <= h - 1) {
+                                if (q < a.cap) { out[(size_t)(2 + cn[j]) * a.cap + q] = l; out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1; }
+                                ++cn[j];
+                                cm[j] |= 1u << kk;
+                            }
+                        }
+                    }
                 }
             }
+            u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * a.cap);
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j)
+                if (j < kmax && j < k && pos + j < a.cap) omask[pos + j] = (u8)cm[j];
         }
+#undef DSM_PICK
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
@@ -1273,7 +1303,7 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * REC_FIELDS * sizeof(P) + 2 * 4 + 4)   // rec x2, rp x2, tpos
+        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) + 2 * 4 + 4)   // rec x2, rp x2, tpos
                    + (u64)nlocal * (sizeof(P) + 1)                             // send
                    + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
@@ -1308,8 +1338,8 @@ class Engine {
         for (int s = 0; s < nlocal; ++s) {
             P *a, *b;
             u32 *r0, *r1, *tp;
-            if (int rc = dalloc(a, (size_t)REC_FIELDS * Fcap)) return rc;
-            if (int rc = dalloc(b, (size_t)REC_FIELDS * Fcap)) return rc;
+            if (int rc = dalloc(a, rec_elems<P>(Fcap))) return rc;
+            if (int rc = dalloc(b, rec_elems<P>(Fcap))) return rc;
             if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
             if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
             if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
@@ -1441,15 +1471,18 @@ class Engine {
         for (int s = 0; s < nlocal && !trie_mode; ++s) {
             const IndexMeta& m = idx[s]->meta;
             P h[REC_FIELDS];
+            for (int f = 0; f < REC_FIELDS; ++f) h[f] = 0;
             h[0] = 0;
             h[1] = (P)(m.n - 1);
+            u8 hmask = 0;
+            int slot = 0;
             for (int a = 0; a < 4; ++a) {
                 u64 lo = m.C[(int)bases[a]], cnt = m.codes[(int)bases[a]].count;  // LF(a,-1), LF(a,n-1)
-                if (cnt) { h[2 + a] = (P)lo; h[6 + a] = (P)(lo + cnt - 1); }
-                else { h[2 + a] = 1; h[6 + a] = 0; }
+                if (cnt) { h[2 + slot] = (P)lo; h[6 + slot] = (P)(lo + cnt - 1); ++slot; hmask |= (u8)(1u << a); }
             }
             for (int f = 0; f < REC_FIELDS; ++f)
                 DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Fcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
+            DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)REC_FIELDS * Fcap, &hmask, 1, hipMemcpyHostToDevice, st));
             const u32 zero = 0;
             DSM_HIP(hipMemcpyAsync(rp[0][s], &zero, sizeof(u32), hipMemcpyHostToDevice, st));
             stats.lf_steps += 8;
@@ -1525,6 +1558,8 @@ class Engine {
             for (int s = 0; s < nlocal && !trie_mode; ++s) {
                 const IndexMeta& m = idx[s]->meta;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
+                ea.sb.one_sb = (m.n >> SB_SHIFT) == 0 ? 1u : 0u;
+                for (int c = 0; c < 4; ++c) ea.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
                 P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);                  // this sample's frequency column
                 u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;                  // children nibble | left char << 4
