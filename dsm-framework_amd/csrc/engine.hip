@@ -448,7 +448,10 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
     u32 ex = block_exclusive_scan<u32>(s, &tot);
     const u32 off = offsets ? offsets[blockIdx.x] : 0u;
     ex += off;
-    if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + tot;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (total) *total = off + tot;
+        o.firstchild[x.F] = off + tot;  // sentinel: the filter of this level runs before the host has seen the total
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const u64 j0 = base + 4 * half;
@@ -1588,6 +1591,14 @@ class Engine {
                 me.freq = fq;
                 hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, fq, me.left);
             }
+            const bool emit_here = !stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi;
+            bool filtered = false;
+            if (emit_here) {
+                int erc = emit_alloc(me, F);
+                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }  // agreed on at the end of the prefix
+                else if (erc) return erc;
+                else filtered = true;
+            }
             const size_t mark2 = arena.off;
             u32* new_slot2 = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
             if (!new_slot2) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
@@ -1609,6 +1620,10 @@ class Engine {
                 exclusive_scan<u32, u32>(adv_sums, adv_sums, nb, scan_tmp, d_totals, st);
                 hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
             }
+            // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
+            if (filtered) {
+                if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
+            }
             DSM_HIP(hipMemcpyAsync(h_totals, d_totals, sizeof(u32), hipMemcpyDeviceToHost, st));
             DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, MAX_LOCAL * sizeof(u32), hipMemcpyDeviceToHost, st));
             DSM_HIP(hipMemcpy2DAsync(h_childmax, sizeof(u64), xrecv[xcur] + bpr - 16, (size_t)bpr, sizeof(u64), (size_t)world, hipMemcpyDeviceToHost, st));
@@ -1622,7 +1637,6 @@ class Engine {
             for (int s = 0; s < nlocal; ++s)
                 if (h_totals[8 + s] > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
-            DSM_HIP(hipMemcpyAsync(me.firstchild + F, &h_totals[0], sizeof(u32), hipMemcpyHostToDevice, st));  // sentinel
             // commit the provisional window at its real size
             arena.off = mark2;
             child.n = Fn;
@@ -1669,10 +1683,9 @@ class Engine {
                     capture->ord.push_back(o);
                 }
             }
-            // ---- output predicates for the nodes of THIS level (their children are known now) -----
-            if (!stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi) {
-                int erc = emit_level(me, F, depth, x, cur, order_mode);
-                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }  // agreed on at the end of the prefix
+            if (filtered) {  // the candidates of this level: totals arrived with the synchronisation above
+                int erc = emit_store(me, F, depth, x, cur, order_mode);
+                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }
                 else if (erc) return erc;
             }
             DSM_HIP(hipGetLastError());
@@ -1733,11 +1746,20 @@ class Engine {
     }
 
     // ---- output predicates and candidate store for the nodes of one level (their children are known) ----
-    int emit_level(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
+    // Two halves: the filter and its scan are queued before the host waits for the width of the next level, so the one
+    // synchronisation per level also returns the candidate totals; the store follows once they are known.
+    FilterArgs filter_args(u32 F, u32 depth, u32 order_mode) const {
         FilterArgs fa;
         fa.F = F; fa.depth = depth; fa.d = d; fa.pmin = prm.pmin; fa.pmax = prm.pmax; fa.mindepth = prm.mindepth;
         fa.emin = prm.emin; fa.emax = prm.emax; fa.exact_order = order_mode;
+        return fa;
+    }
+    int emit_alloc(LevelHost& me, u32 F) {  // before the provisional window of the next level is taken from the arena
         EARENA_GET(me.cand_flag, u8, F);
+        return 0;
+    }
+    int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
+        const FilterArgs fa = filter_args(F, depth, order_mode);
         const bool one = d == 1;
         hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
                            me.cand_flag, one ? (u64*)nullptr : cand_key);
@@ -1749,7 +1771,12 @@ class Engine {
             exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
             DSM_HIP(hipMemcpyAsync(h_totals + 300, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
         }
-        DSM_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    int emit_store(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {  // after the level's synchronisation
+        const FilterArgs fa = filter_args(F, depth, order_mode);
+        const bool one = d == 1;
+        u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         u64 tot = 0;
         memcpy(&tot, h_totals + 300, sizeof tot);
         me.ncand = (u32)(tot & 0xFFFFFFFFu);
