@@ -430,59 +430,102 @@ struct AdvanceOut {
     const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
 };
 
+// how many samples keep each child of parent u (0 = the slot is not a union node)
+template <typename P>
+__device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
+    const u32 world = x.d / x.nlocal;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nT4[c] = 0;
+    for (u32 r = 0; r < world; ++r) {
+        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
+        for (u32 l = 0; l < x.nlocal; ++l) {
+            const u32 m = pb[(u64)l * x.F + u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nT4[c] += (m >> c) & 1u;
+        }
+    }
+}
+
+// Down-sweep, one thread per parent (a block covers its tile of ADV_TILE slots as two pieces of 256 parents).  The children
+// of a lane are written child-slot by child-slot: most parents have one child, so the lanes of a pass write neighbouring
+// entries of the new level's arrays.
+constexpr int ADV_PIECES = ADV_TILE / 1024;
 template <typename P>
 __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __restrict__ offsets, AdvanceOut o, u32* __restrict__ total) {
-    const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
-    const u64 slots = x.F * 4;
-    u32 nTs[ADV_SLOTS];
-    u32 s = 0;
-    if (o.sinfo) {  // evaluated by the reduce pass
+    __shared__ u32 wsum[ADV_PIECES][4];
+    const u32 F = (u32)x.F;
+    const u32 u0 = blockIdx.x * (ADV_TILE / 4);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 nT4[ADV_PIECES][4], excl[ADV_PIECES];
 #pragma unroll
-        for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] = base + k < slots ? (u32)o.sinfo[base + k] : 0u;
-    } else {
-        slots_eval8<P>(x, base >> 2, nTs);
-    }
+    for (int pc = 0; pc < ADV_PIECES; ++pc) {
+        const u32 u = u0 + pc * 256 + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < ADV_SLOTS; ++k) s += nTs[k] != 0;
-    u32 tot;
-    u32 ex = block_exclusive_scan<u32>(s, &tot);
-    const u32 off = offsets ? offsets[blockIdx.x] : 0u;
-    ex += off;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        if (total) *total = off + tot;
-        o.firstchild[x.F] = off + tot;  // sentinel: the filter of this level runs before the host has seen the total
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const u64 j0 = base + 4 * half;
-        if (j0 >= slots) break;
-        const u32 u = (u32)(j0 >> 2);
-        o.firstchild[u] = ex;
-        u32 nc = 0, lastT = 0;
-        const u32 v0 = ex;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = 4 * half + c;
-            if (!nTs[k]) continue;
-            const u32 v = ex++;
-            ++nc;
-            lastT = nTs[k];
-            o.slot[v] = (u32)(j0 + c);
-            o.nT[v] = (u16)nTs[k];
-        }
-        if (nc) {
-            for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
-                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
-                u32 h = m ? o.tpos[sl][u] : 0u;
-                u32 v = v0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!nTs[4 * half + c]) continue;
-                    o.rp[sl][v++] = ((m >> c) & 1u) ? h++ : DEAD;
-                }
+        for (int c = 0; c < 4; ++c) nT4[pc][c] = 0;
+        if (u < F) {
+            if (o.sinfo) {
+                const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
+                nT4[pc][0] = q.x & 0xFFFFu; nT4[pc][1] = q.x >> 16; nT4[pc][2] = q.y & 0xFFFFu; nT4[pc][3] = q.y >> 16;
+            } else {
+                parent_eval<P>(x, u, nT4[pc]);
             }
         }
+    }
+#pragma unroll
+    for (int pc = 0; pc < ADV_PIECES; ++pc) {
+        const u32 k = (nT4[pc][0] != 0) + (nT4[pc][1] != 0) + (nT4[pc][2] != 0) + (nT4[pc][3] != 0);
+        const u64 lt = (1ull << lane) - 1;
+        u32 e = 0, ws = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const u64 m = __ballot((k >> b) & 1u);
+            e += (u32)__popcll(m & lt) << b;
+            ws += (u32)__popcll(m) << b;
+        }
+        excl[pc] = e;
+        if (lane == 0) wsum[pc][w] = ws;
+    }
+    __syncthreads();
+    u32 run = offsets ? offsets[blockIdx.x] : 0u;
+#pragma unroll
+    for (int pc = 0; pc < ADV_PIECES; ++pc) {
+        const u32 u = u0 + pc * 256 + threadIdx.x;
+        u32 base = run, tot = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { const u32 t = wsum[pc][kk]; if (kk < w) base += t; tot += t; }
+        run += tot;
+        if (u >= F) continue;
+        const u32 v0 = base + excl[pc];
+        u32 pres = 0, lastT = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (nT4[pc][c]) { pres |= 1u << c; lastT = nT4[pc][c]; }
+        const u32 nc = __popc(pres);
+        o.firstchild[u] = v0;
         o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+        if (!nc) continue;
+        u32 mm = pres;
+        for (u32 j = 0; j < nc; ++j) {
+            const u32 c = (u32)__ffs(mm) - 1u;
+            mm &= mm - 1;
+            const u32 t = c == 0 ? nT4[pc][0] : (c == 1 ? nT4[pc][1] : (c == 2 ? nT4[pc][2] : nT4[pc][3]));
+            o.slot[v0 + j] = 4u * u + c;
+            o.nT[v0 + j] = (u16)t;
+        }
+        for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
+            const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
+            const u32 h = m ? o.tpos[sl][u] : 0u;
+            u32* rp = o.rp[sl];
+            u32 m2 = pres;
+            for (u32 j = 0; j < nc; ++j) {
+                const u32 c = (u32)__ffs(m2) - 1u;
+                m2 &= m2 - 1;
+                rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (total) *total = run;
+        o.firstchild[F] = run;  // sentinel: the filter of this level runs before the host has seen the total
     }
 }
 
@@ -581,7 +624,10 @@ struct FilterArgs {
 };
 
 // output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
-// within 1e-9 of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
+// within ENT_MARGIN of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
+// The device value uses the hardware log2 (v_log_f32, 1 ulp: at most 2^-18 absolute for arguments below 2^64), so it
+// is off by less than 1e-5; the margin leaves a factor of ten.
+constexpr double ENT_MARGIN = 1e-4;
 // key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
 template <typename P>
 __global__ void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT,
@@ -604,13 +650,13 @@ __global__ void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT,
                 u32 lg = x_pl<P>(x, g, v) >> 4;
                 l = l == 0xFF ? lg : (l == lg ? l : 5u);
                 sumN += f;
-                if (a.emax > 0) s += (double)(f + 1) * log2((double)(f + 1));
+                if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
             }
         }
         if (l >= 1 && l <= 4) out = false;
         if (out && a.emax > 0) {
-            double e = log2((double)sumN) - s / (double)sumN;
-            if (e < a.emin - 1e-9 || e > a.emax + 1e-9) out = false;
+            double e = (double)__log2f((float)sumN) - s / (double)sumN;
+            if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) out = false;
         }
     }
     cand[v] = out ? 1 : 0;

@@ -1,6 +1,8 @@
 // scan.h -- device-wide exclusive prefix sum (reduce / scan-of-sums / downsweep), wave64 shuffles.
 // Used for frontier compaction, candidate offsets and the per-block symbol counts of the index.
 #pragma once
+#include <cstdint>
+
 #include "common.h"
 
 namespace dsm {
@@ -40,38 +42,62 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* tot) {
     return base + inc - v;
 }
 
-template <typename InT, typename OutT>
+// A thread owns SCAN_ITEMS consecutive elements.  With VEC (both arrays 16-byte aligned) a full group moves as one or two
+// wide accesses per thread; element-wise accesses at a stride of SCAN_ITEMS elements would touch every line of the tile
+// SCAN_ITEMS times.
+template <typename T>
+struct alignas(sizeof(T) * SCAN_ITEMS >= 16 ? 16 : sizeof(T) * SCAN_ITEMS) ScanGroup { T v[SCAN_ITEMS]; };
+
+template <bool VEC, typename InT, typename OutT>
+__device__ __forceinline__ void scan_load(const InT* __restrict__ in, size_t base, size_t n, OutT v[SCAN_ITEMS]) {
+    if (VEC && base + SCAN_ITEMS <= n) {
+        const ScanGroup<InT> g = *reinterpret_cast<const ScanGroup<InT>*>(in + base);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (OutT)g.v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = base + k < n ? (OutT)in[base + k] : (OutT)0;
+    }
+}
+
+template <bool VEC, typename InT, typename OutT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const InT* __restrict__ in, size_t n, OutT* __restrict__ sums) {
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    OutT v[SCAN_ITEMS];
+    scan_load<VEC, InT, OutT>(in, base, n, v);
     OutT s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += (OutT)in[base + k];
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
     OutT tot;
     block_exclusive_scan<OutT>(s, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
 // out[i] = offsets[block] + exclusive prefix inside the tile.  in/out may alias.
-template <typename InT, typename OutT>
+template <bool VEC, typename InT, typename OutT>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const InT* in, OutT* out, size_t n, const OutT* __restrict__ offsets,
                                                                 OutT* __restrict__ total) {
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     OutT v[SCAN_ITEMS];
+    scan_load<VEC, InT, OutT>(in, base, n, v);
     OutT s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = base + k < n ? (OutT)in[base + k] : (OutT)0;
-        s += v[k];
-    }
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
     OutT tot;
     OutT ex = block_exclusive_scan<OutT>(s, &tot);
     OutT off = offsets ? offsets[blockIdx.x] : (OutT)0;
     ex += off;
+    if (VEC && base + SCAN_ITEMS <= n) {
+        ScanGroup<OutT> g;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = ex;
-        ex += v[k];
+        for (int k = 0; k < SCAN_ITEMS; ++k) { g.v[k] = ex; ex += v[k]; }
+        *reinterpret_cast<ScanGroup<OutT>*>(out + base) = g;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (base + k < n) out[base + k] = ex;
+            ex += v[k];
+        }
     }
     if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = off + tot;
 }
@@ -90,17 +116,21 @@ inline size_t scan_tmp_elems(size_t n) {
 template <typename InT, typename OutT>
 inline void exclusive_scan(const InT* in, OutT* out, size_t n, OutT* tmp, OutT* d_total, hipStream_t st) {
     if (n == 0) {
-        if (d_total) hipMemsetAsync(d_total, 0, sizeof(OutT), st);
+        if (d_total) (void)hipMemsetAsync(d_total, 0, sizeof(OutT), st);
         return;
     }
+    const bool vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
     size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nb == 1) {
-        hipLaunchKernelGGL((scan_down_kernel<InT, OutT>), dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)nullptr, d_total);
+        if (vec) hipLaunchKernelGGL((scan_down_kernel<true, InT, OutT>), dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)nullptr, d_total);
+        else hipLaunchKernelGGL((scan_down_kernel<false, InT, OutT>), dim3(1), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)nullptr, d_total);
         return;
     }
-    hipLaunchKernelGGL((scan_reduce_kernel<InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
+    if (vec) hipLaunchKernelGGL((scan_reduce_kernel<true, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
+    else hipLaunchKernelGGL((scan_reduce_kernel<false, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
     exclusive_scan<OutT, OutT>(tmp, tmp, nb, tmp + nb, d_total, st);
-    hipLaunchKernelGGL((scan_down_kernel<InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);
+    if (vec) hipLaunchKernelGGL((scan_down_kernel<true, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);
+    else hipLaunchKernelGGL((scan_down_kernel<false, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);
 }
 
 }  // namespace dsm
