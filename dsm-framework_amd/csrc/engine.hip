@@ -124,6 +124,12 @@ __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
 constexpr u32 DEAD = 0xFFFFFFFFu;
 
+// Thread-per-node kernels do little per node; a thread takes NPT nodes a grid-width apart (coalescing is kept) and issues
+// all their loads before using any, so a wave has several lines in flight and the grid is NPT times smaller.
+constexpr int NPT = 4;
+static inline dim3 grid_npt(u64 n) { return dim3((unsigned)((n + 256ull * NPT - 1) / (256ull * NPT))); }
+
+
 struct ExpandArgs {
     u32 F;            // frontier width
     u32 cap;          // record capacity (stride of both record buffers)
@@ -630,37 +636,52 @@ struct FilterArgs {
 constexpr double ENT_MARGIN = 1e-4;
 // key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
 template <typename P>
-__global__ void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT,
-                              const u32* __restrict__ firstchild, const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= a.F) return;
-    bool out = true;
-    const u32 t = nT[v];
-    if (a.depth < a.mindepth) out = false;
-    if (a.pmax != 0 && t > a.pmax) out = false;
-    if (t < a.pmin) out = false;
-    if (firstchild[v + 1] - firstchild[v] == 1 && samechild[v]) out = false;
-    if (out) {  // merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
-        u64 sumN = a.d;
-        double s = 0;
-        u32 l = 0xFF;
-        for (u32 g = 0; g < a.d; ++g) {
-            u64 f = (u64)x_freq<P>(x, g, v);
-            if (f) {
-                u32 lg = x_pl<P>(x, g, v) >> 4;
-                l = l == 0xFF ? lg : (l == lg ? l : 5u);
-                sumN += f;
-                if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, const u32* __restrict__ firstchild,
+                                                     const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
+    const u32 stride = gridDim.x * blockDim.x;
+    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 t[NPT];
+    bool out[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {  // the cheap predicates of all NPT nodes first: their loads are in flight together
+        const u32 v = v0 + i * stride, vc = v < a.F ? v : 0u;
+        t[i] = nT[vc];
+        const u32 nc = firstchild[vc + 1] - firstchild[vc];
+        const u32 same = samechild[vc];
+        bool o = v < a.F;
+        if (a.depth < a.mindepth) o = false;
+        if (a.pmax != 0 && t[i] > a.pmax) o = false;
+        if (t[i] < a.pmin) o = false;
+        if (nc == 1 && same) o = false;
+        out[i] = o;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 v = v0 + i * stride;
+        if (out[i]) {  // merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
+            u64 sumN = a.d;
+            double s = 0;
+            u32 l = 0xFF;
+            for (u32 g = 0; g < a.d; ++g) {
+                u64 f = (u64)x_freq<P>(x, g, v);
+                if (f) {
+                    u32 lg = x_pl<P>(x, g, v) >> 4;
+                    l = l == 0xFF ? lg : (l == lg ? l : 5u);
+                    sumN += f;
+                    if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+                }
+            }
+            if (l >= 1 && l <= 4) out[i] = false;
+            if (out[i] && a.emax > 0) {
+                double e = (double)__log2f((float)sumN) - s / (double)sumN;
+                if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) out[i] = false;
             }
         }
-        if (l >= 1 && l <= 4) out = false;
-        if (out && a.emax > 0) {
-            double e = (double)__log2f((float)sumN) - s / (double)sumN;
-            if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) out = false;
+        if (v < a.F) {
+            cand[v] = out[i] ? 1 : 0;
+            if (key) key[v] = out[i] ? (1ull | ((u64)t[i] << 32)) : 0ull;  // d == 1: one pair per candidate, the flag scan is enough
         }
     }
-    cand[v] = out ? 1 : 0;
-    if (key) key[v] = out ? (1ull | ((u64)t << 32)) : 0ull;  // d == 1: one pair per candidate, the flag scan is enough
 }
 
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
@@ -710,25 +731,55 @@ __global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict_
 // ---- subtree aggregates over the retained levels ------------------------------------------------
 // bottom-up: agg[v] = own[v] + sum over children agg_child          (children of v: [fc[v], fc[v+1]) )
 template <typename T, typename OwnT>
-__global__ void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const T* __restrict__ child_agg, T* __restrict__ agg) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= F) return;
-    T s = own ? (T)own[v] : (T)1;
-    u32 fc = firstchild[v], nc = firstchild[v + 1] - fc;
-    for (u32 k = 0; k < nc; ++k) s += child_agg[fc + k];
-    agg[v] = s;
+__global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const T* __restrict__ child_agg,
+                                                 T* __restrict__ agg) {
+    const u32 stride = gridDim.x * blockDim.x;
+    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 fc[NPT], nc[NPT];
+    T s[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
+        fc[i] = firstchild[vc];
+        nc[i] = v < F ? firstchild[vc + 1] - fc[i] : 0u;
+        s[i] = own ? (T)own[vc] : (T)1;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        if (nc[i]) s[i] += child_agg[fc[i]];   // nearly every node has one child: fetch it with the batch
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        for (u32 k = 1; k < nc[i]; ++k) s[i] += child_agg[fc[i] + k];
+        const u32 v = v0 + i * stride;
+        if (v < F) agg[v] = s[i];
+    }
 }
 // top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]
 template <typename T>
-__global__ void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild, const T* __restrict__ child_agg,
-                            T* __restrict__ child_start) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= F) return;
-    T s = start[v] + lead;
-    u32 fc = firstchild[v], nc = firstchild[v + 1] - fc;
-    for (u32 k = 0; k < nc; ++k) {
-        child_start[fc + k] = s;
-        s += child_agg[fc + k];
+__global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild,
+                                                   const T* __restrict__ child_agg, T* __restrict__ child_start) {
+    const u32 stride = gridDim.x * blockDim.x;
+    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 fc[NPT], nc[NPT];
+    T s[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
+        fc[i] = firstchild[vc];
+        nc[i] = v < F ? firstchild[vc + 1] - fc[i] : 0u;
+        s[i] = start[vc] + lead;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        if (nc[i]) child_start[fc[i]] = s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        for (u32 k = 1; k < nc[i]; ++k) {
+            s[i] += child_agg[fc[i] + k - 1];
+            child_start[fc[i] + k] = s[i];
+        }
     }
 }
 
@@ -1807,7 +1858,7 @@ class Engine {
     int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
         const FilterArgs fa = filter_args(F, depth, order_mode);
         const bool one = d == 1;
-        hipLaunchKernelGGL((filter_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
+        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
                            me.cand_flag, one ? (u64*)nullptr : cand_key);
         u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         if (one) {
@@ -1858,7 +1909,7 @@ class Engine {
                 EARENA_GET(L[l].cand_flag, u8, L[l].n);
                 DSM_HIP(hipMemsetAsync(L[l].cand_flag, 0, L[l].n, st));
             }
-            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
+            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
         }
         // top-down: start offsets, two rolling arrays
         u32 *t_level, *t_cidx;
@@ -1873,7 +1924,7 @@ class Engine {
         for (u32 l = 0; l + 1 < nlev; ++l) {
             u32* s_cur = startbuf[l & 1];
             u32* s_next = startbuf[(l + 1) & 1];
-            hipLaunchKernelGGL((down_kernel<u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l + 1].sub, s_next);
+            hipLaunchKernelGGL((down_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l + 1].sub, s_next);
             if (L[l + 1].ncand)
                 hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, s_next, L[l + 1].sub, l + 1,
                                    t_level, t_cidx);
@@ -1963,25 +2014,25 @@ class Engine {
             ARENA_GET(L[l].off, u64, L[l].n);
         }
         for (u32 l = nlev; l-- > 0;)  // subtree node counts
-            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild,
+            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild,
                                l + 1 < nlev ? L[l + 1].sz : nullptr, L[l].sz);
         {  // pre-order numbers: pre(child_k) = pre(v) + 1 + sum sz(earlier siblings); root pre = -1
             u64 m1 = ~0ull;
             DSM_HIP(hipMemcpyAsync(L[0].pre, &m1, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l + 1].sz, L[l + 1].pre);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l + 1].sz, L[l + 1].pre);
         }
         for (u32 l = 1; l < nlev; ++l)
             hipLaunchKernelGGL((stream_own_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, (const P*)L[l].freq, L[l].pre, L[l].sz, L[l].own);
         DSM_HIP(hipMemsetAsync(L[0].own, 0, 8, st));
         for (u32 l = nlev; l-- > 0;)  // subtree bytes
-            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild,
+            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild,
                                l + 1 < nlev ? L[l + 1].bytes : nullptr, L[l].bytes);
         {  // byte offsets: off(child_k) = off(v) + 2 + sum bytes(earlier siblings); root off = -2
             u64 m2 = ~0ull - 1;
             DSM_HIP(hipMemcpyAsync(L[0].off, &m2, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l + 1].bytes, L[l + 1].off);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l + 1].bytes, L[l + 1].off);
         }
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
