@@ -434,6 +434,10 @@ struct AdvanceOut {
     const u32* const* tpos;
     u32 nlocal, rank;
     const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
+    // what the host needs after the level, written straight into pinned host memory by the last block (no copies):
+    u32* h_totals;       // [0] = nodes of the new level, [8 + s] = child records allocated for local sample s
+    u64* h_childmax;     // [r] = largest child frequency reported by rank r
+    u32* alloc;          // the allocation counters of the expand kernels (cleared here for the next level)
 };
 
 // how many samples keep each child of parent u (0 = the slot is not a union node)
@@ -529,9 +533,16 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        if (total) *total = run;
-        o.firstchild[F] = run;  // sentinel: the filter of this level runs before the host has seen the total
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) {
+            if (total) *total = run;
+            o.firstchild[F] = run;  // sentinel: the filter of this level runs before the host has seen the total
+            o.h_totals[0] = run;
+        }
+        for (u32 sl = threadIdx.x; sl < o.nlocal; sl += blockDim.x) { o.h_totals[8 + sl] = o.alloc[sl]; o.alloc[sl] = 0; }
+        const u32 world = x.d / x.nlocal;
+        for (u32 r = threadIdx.x; r < world; r += blockDim.x)
+            o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr + x.bpr - 16);
     }
 }
 
@@ -1558,6 +1569,7 @@ class Engine {
         std::vector<LevelHost> L;
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
+        DSM_HIP(hipMemsetAsync(d_alloc, 0, MAX_LOCAL * sizeof(u32), st));  // from here on the advance down-sweep clears them
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -1639,7 +1651,6 @@ class Engine {
                 ea.allowed = (depth >= prm.maxdepth || depth >= expand_cap) ? 0u : 15u;  // EnumerateQuery.cpp:153
                 ea.symbol_phase = 1;
             }
-            DSM_HIP(hipMemsetAsync(d_alloc, 0, MAX_LOCAL * sizeof(u32), st));
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             DSM_HIP(hipEventRecord(ea0, st));
@@ -1704,6 +1715,7 @@ class Engine {
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
+            ao.h_totals = h_totals; ao.h_childmax = h_childmax; ao.alloc = d_alloc;
             ao.rp = d_rp_tab[nxt];
             ao.tpos = d_tpos_tab;
             if (nb == 1) {
@@ -1721,9 +1733,6 @@ class Engine {
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
             }
-            DSM_HIP(hipMemcpyAsync(h_totals, d_totals, sizeof(u32), hipMemcpyDeviceToHost, st));
-            DSM_HIP(hipMemcpyAsync(h_totals + 8, d_alloc, MAX_LOCAL * sizeof(u32), hipMemcpyDeviceToHost, st));
-            DSM_HIP(hipMemcpy2DAsync(h_childmax, sizeof(u64), xrecv[xcur] + bpr - 16, (size_t)bpr, sizeof(u64), (size_t)world, hipMemcpyDeviceToHost, st));
             DSM_HIP(hipStreamSynchronize(st));
             const u32 Fn = h_totals[0];
             {
@@ -1862,11 +1871,9 @@ class Engine {
                            me.cand_flag, one ? (u64*)nullptr : cand_key);
         u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         if (one) {
-            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
-            DSM_HIP(hipMemcpyAsync(h_totals + 300, d_totals + 2, sizeof(u32), hipMemcpyDeviceToHost, st));
+            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), h_totals + 300, st);  // total lands in pinned host memory
         } else {
-            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-            DSM_HIP(hipMemcpyAsync(h_totals + 300, d_totals64, sizeof(u64), hipMemcpyDeviceToHost, st));
+            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, reinterpret_cast<u64*>(h_totals + 300), st);
         }
         return 0;
     }
