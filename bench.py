@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rlen", type=int, default=100)
     ap.add_argument("--genome", type=int, default=50_000_000)
     ap.add_argument("--sub-rate", type=float, default=0.005)
-    ap.add_argument("--prefix-len", type=int, default=-1, help="k-mer prefix length of the chunks; default 1 (N<=4) / 2 (N>4)")
+    ap.add_argument("--prefix-len", type=int, default=-1, help="k-mer prefix length of the chunks; default 1")
     ap.add_argument("--fmin", type=int, default=10)
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
@@ -141,7 +141,10 @@ def main():
     path = paths[0]
     ixs = [pydsm.Index(pth, device=local) for pth in paths]
     ix = ixs[0]
-    plen = args.prefix_len if args.prefix_len >= 0 else (1 if world <= 4 else 2)  # >= world prefixes so every rank owns some output
+    # One-letter prefixes at every N: a level costs a fixed ~50 us of launches (plus one all-gather when N > 1), and 16
+    # two-letter prefixes have four times the levels (measured at N=1: 290 vs 353 ms per pass).  With more ranks than
+    # prefixes some ranks emit nothing; that costs less than the extra levels.
+    plen = args.prefix_len if args.prefix_len >= 0 else 1
     prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
     pmin = args.pmin if args.pmin > 0 else (1 if world * args.nlocal == 1 else 2)
 
