@@ -123,6 +123,13 @@ template <typename P>
 __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
 constexpr u32 DEAD = 0xFFFFFFFFu;
+// Child records are allocated per block of 256 parents.  A block reserves a window of ALLOC_WIN handles when it starts, so
+// the atomic's round trip is over long before the count is known; only a block that needs more takes a second, exact
+// allocation (and leaves its window unused).  The counters are spread over up to ALLOC_SHARDS regions of the record
+// buffer, each on its own 128-byte line: one word takes about 9e7 atomics/s, less than the blocks of the deep levels issue.
+constexpr u32 ALLOC_WIN = 320;
+constexpr u32 ALLOC_SHARDS = 32;
+constexpr u32 ALLOC_PITCH = 32;    // u32 per region counter
 
 // Thread-per-node kernels do little per node; a thread takes NPT nodes a grid-width apart (coalescing is kept) and issues
 // all their loads before using any, so a wave has several lines in flight and the grid is NPT times smaller.
@@ -137,6 +144,8 @@ struct ExpandArgs {
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
     u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
+    u32 ns_mask;      // allocation regions - 1 (a block uses region blockIdx & ns_mask)
+    u32 region;       // handles per region
     SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
@@ -153,6 +162,9 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                                                      u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
                                                      u32* __restrict__ blockcnt, unsigned long long* __restrict__ childmax) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 shard = blockIdx.x & a.ns_mask;
+    u32 early = 0;
+    if (threadIdx.x == 0) early = atomicAdd(alloc + shard * ALLOC_PITCH, ALLOC_WIN);
     u64 n_lf = 0, n_rank = 0;
     u32 lines = 0;
     u32 r = DEAD;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     }
     // ---- compact allocation of the child records: block scan + one atomic per block --------------
     __shared__ u32 wtot[4];
-    __shared__ u32 sbase;
+    __shared__ u32 sbase, slimit;
     __shared__ u64 red[4][4];
     const u32 k = __popc(present);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -246,7 +258,8 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        sbase = tot ? atomicAdd(alloc, tot) : 0u;
+        sbase = shard * a.region + (tot <= ALLOC_WIN ? early : atomicAdd(alloc + shard * ALLOC_PITCH, tot));
+        slimit = (shard + 1) * a.region;
         if (blockcnt) blockcnt[blockIdx.x] = tot;  // single sample: these are the alive slots of the block's 1024 slots
     }
     if (threadIdx.x < 4) {
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     }
     __syncthreads();
     u32 pos = sbase + excl;
+    const u32 limit = slimit;  // a region that overflows is detected by the host from its counter
     for (int q = 0; q < w; ++q) pos += wtot[q];
     if (i < a.F) {
         if (present) {
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         for (u32 j = 0; j < 4; ++j) {
             if (j < kmax && j < k) {
                 const u32 c = cj[j], q = pos + j;
-                if (q < a.cap) { out[q] = DSM_PICK(Rsp, c); out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1; }  // overflow is detected by the host from *alloc
+                if (q < limit) { out[q] = DSM_PICK(Rsp, c); out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1; }
             }
         }
         if (present) {
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                             const u32 c = cj[j], q = pos + j;
                             const P l = DSM_PICK(lo, c), h = DSM_PICK(hi, c);
                             if (l <= h - 1) {
-                                if (q < a.cap) { out[(size_t)(2 + cn[j]) * a.cap + q] = l; out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1; }
+                                if (q < limit) { out[(size_t)(2 + cn[j]) * a.cap + q] = l; out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1; }
                                 ++cn[j];
                                 cm[j] |= 1u << kk;
                             }
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
             u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * a.cap);
 #pragma unroll
             for (u32 j = 0; j < 4; ++j)
-                if (j < kmax && j < k && pos + j < a.cap) omask[pos + j] = (u8)cm[j];
+                if (j < kmax && j < k && pos + j < limit) omask[pos + j] = (u8)cm[j];
         }
 #undef DSM_PICK
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
@@ -433,9 +447,11 @@ struct AdvanceOut {
     u32* const* rp;          // device tables of nlocal pointers
     const u32* const* tpos;
     u32 nlocal, rank;
+    u32 cap;           // entries of the new level's arrays: a wider level is reported through the total, not written
     const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
     // what the host needs after the level, written straight into pinned host memory by the last block (no copies):
-    u32* h_totals;       // [0] = nodes of the new level, [8 + s] = child records allocated for local sample s
+    u32* h_totals;       // [0] = nodes of the new level
+    u32* h_alloc;        // [s * ALLOC_SHARDS + region] = handles taken from that region for local sample s
     u64* h_childmax;     // [r] = largest child frequency reported by rank r
     u32* alloc;          // the allocation counters of the expand kernels (cleared here for the next level)
 };
@@ -518,8 +534,10 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             const u32 c = (u32)__ffs(mm) - 1u;
             mm &= mm - 1;
             const u32 t = c == 0 ? nT4[pc][0] : (c == 1 ? nT4[pc][1] : (c == 2 ? nT4[pc][2] : nT4[pc][3]));
-            o.slot[v0 + j] = 4u * u + c;
-            o.nT[v0 + j] = (u16)t;
+            if (v0 + j < o.cap) {
+                o.slot[v0 + j] = 4u * u + c;
+                o.nT[v0 + j] = (u16)t;
+            }
         }
         for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
             const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
@@ -529,7 +547,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             for (u32 j = 0; j < nc; ++j) {
                 const u32 c = (u32)__ffs(m2) - 1u;
                 m2 &= m2 - 1;
-                rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+                if (v0 + j < o.cap) rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
             }
         }
     }
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             o.firstchild[F] = run;  // sentinel: the filter of this level runs before the host has seen the total
             o.h_totals[0] = run;
         }
-        for (u32 sl = threadIdx.x; sl < o.nlocal; sl += blockDim.x) { o.h_totals[8 + sl] = o.alloc[sl]; o.alloc[sl] = 0; }
+        for (u32 q = threadIdx.x; q < o.nlocal * ALLOC_SHARDS; q += blockDim.x) { o.h_alloc[q] = o.alloc[q * ALLOC_PITCH]; o.alloc[q * ALLOC_PITCH] = 0; }
         const u32 world = x.d / x.nlocal;
         for (u32 r = threadIdx.x; r < world; r += blockDim.x)
             o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr + x.bpr - 16);
@@ -1312,6 +1330,9 @@ class Engine {
 
     // frontier buffers
     u32 Fcap = 0;
+    u32 Rcap = 0;             // handles of a record buffer (Fcap plus the slack of the windowed allocation)
+    u32 ns_shards = 1, region = 0;
+    u32* h_alloc = nullptr;   // pinned [nlocal][ALLOC_SHARDS]
     std::vector<P*> rec[2];     // compact child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
     std::vector<u32*> tpos;     // handle of the first child record of every node of the level being expanded
@@ -1347,6 +1368,7 @@ class Engine {
     ~Engine() {
         for (void* p : owned) (void)hipFree(p);
         if (h_totals) (void)hipHostFree(h_totals);
+        if (h_alloc) (void)hipHostFree(h_alloc);
         if (h_childmax) (void)hipHostFree(h_childmax);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1414,7 +1436,7 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) + 2 * 4 + 4)   // rec x2, rp x2, tpos
+        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) * 9 / 4 + 2 * 4 + 4)   // rec x2 (with the window slack), rp x2, tpos
                    + (u64)nlocal * (sizeof(P) + 1)                             // send
                    + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
@@ -1445,12 +1467,21 @@ class Engine {
             if (int rc = agree_min(mine, &agreed)) return rc;
             Fcap = (u32)agreed;
         }
+        // Record handles: a level reserves at most ALLOC_WIN per 256 parents plus, for blocks that outgrow their window, their
+        // exact child count -- never more than 1.25 * parents + children + one window.
+        {
+            const u64 rc64 = (u64)Fcap * 9 / 4 + 4096;
+            Rcap = rc64 > 0xFFFFFF00ull ? 0xFFFFFF00u : (u32)rc64;
+            ns_shards = 1;
+            while (ns_shards < ALLOC_SHARDS && Rcap / (ns_shards * 2) >= 65536) ns_shards *= 2;
+            region = Rcap / ns_shards;
+        }
         const u64 slots = (u64)Fcap * 4;
         for (int s = 0; s < nlocal; ++s) {
             P *a, *b;
             u32 *r0, *r1, *tp;
-            if (int rc = dalloc(a, rec_elems<P>(Fcap))) return rc;
-            if (int rc = dalloc(b, rec_elems<P>(Fcap))) return rc;
+            if (int rc = dalloc(a, rec_elems<P>(Rcap))) return rc;
+            if (int rc = dalloc(b, rec_elems<P>(Rcap))) return rc;
             if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
             if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
             if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
@@ -1479,7 +1510,9 @@ class Engine {
         if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
-        if (int rc = dalloc(d_alloc, MAX_LOCAL)) return rc;
+        if (int rc = dalloc(d_alloc, (size_t)nlocal * ALLOC_SHARDS * ALLOC_PITCH)) return rc;
+        DSM_HIP(hipHostMalloc((void**)&h_alloc, (size_t)nlocal * ALLOC_SHARDS * sizeof(u32)));
+        memset(h_alloc, 0, (size_t)nlocal * ALLOC_SHARDS * sizeof(u32));
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 320 * sizeof(u32)));
@@ -1569,7 +1602,7 @@ class Engine {
         std::vector<LevelHost> L;
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
-        DSM_HIP(hipMemsetAsync(d_alloc, 0, MAX_LOCAL * sizeof(u32), st));  // from here on the advance down-sweep clears them
+        DSM_HIP(hipMemsetAsync(d_alloc, 0, (size_t)nlocal * ALLOC_SHARDS * ALLOC_PITCH * sizeof(u32), st));  // from here on the advance down-sweep clears them
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -1593,8 +1626,8 @@ class Engine {
                 if (cnt) { h[2 + slot] = (P)lo; h[6 + slot] = (P)(lo + cnt - 1); ++slot; hmask |= (u8)(1u << a); }
             }
             for (int f = 0; f < REC_FIELDS; ++f)
-                DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Fcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
-            DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)REC_FIELDS * Fcap, &hmask, 1, hipMemcpyHostToDevice, st));
+                DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Rcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
+            DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)REC_FIELDS * Rcap, &hmask, 1, hipMemcpyHostToDevice, st));
             const u32 zero = 0;
             DSM_HIP(hipMemcpyAsync(rp[0][s], &zero, sizeof(u32), hipMemcpyHostToDevice, st));
             stats.lf_steps += 8;
@@ -1640,7 +1673,8 @@ class Engine {
             u8* send = world > 1 ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
-            ea.F = F; ea.cap = Fcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
+            ea.F = F; ea.cap = Rcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
+            ea.ns_mask = ns_shards - 1; ea.region = region;
             unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send + bpr - 16);
             DSM_HIP(hipMemsetAsync(d_childmax, 0, 16, st));
             if (depth < prefix.size()) {
@@ -1674,7 +1708,7 @@ class Engine {
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
                 P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);                  // this sample's frequency column
                 u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;                  // children nibble | left char << 4
-                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + s,
+                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + (size_t)s * ALLOC_SHARDS * ALLOC_PITCH,
                                    tpos[s], cf, cl, ea, d_counters, (d == 1 && !trie_mode) ? blockcnt : (u32*)nullptr, d_childmax);
                 ++stats.expand_launches;
             }
@@ -1715,7 +1749,8 @@ class Engine {
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
-            ao.h_totals = h_totals; ao.h_childmax = h_childmax; ao.alloc = d_alloc;
+            ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
+            ao.h_totals = h_totals; ao.h_alloc = h_alloc; ao.h_childmax = h_childmax; ao.alloc = d_alloc;
             ao.rp = d_rp_tab[nxt];
             ao.tpos = d_tpos_tab;
             if (nb == 1) {
@@ -1740,8 +1775,8 @@ class Engine {
                 for (int r = 0; r < world; ++r) mx = h_childmax[r] > mx ? h_childmax[r] : mx;
                 w16 = mx < 65535 && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
             }
-            for (int s = 0; s < nlocal; ++s)
-                if (h_totals[8 + s] > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+            for (size_t q = 0; q < (size_t)nlocal * ALLOC_SHARDS && !trie_mode; ++q)
+                if (h_alloc[q] > region) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             // commit the provisional window at its real size
             arena.off = mark2;
