@@ -449,12 +449,25 @@ struct AdvanceOut {
     u32 nlocal, rank;
     u32 cap;           // entries of the new level's arrays: a wider level is reported through the total, not written
     const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
-    // what the host needs after the level, written straight into pinned host memory by the last block (no copies):
+    // what the host needs after the level, gathered by the last block (publish_kernel hands it to the host):
     u32* h_totals;       // [0] = nodes of the new level
     u32* h_alloc;        // [s * ALLOC_SHARDS + region] = handles taken from that region for local sample s
     u64* h_childmax;     // [r] = largest child frequency reported by rank r
     u32* alloc;          // the allocation counters of the expand kernels (cleared here for the next level)
 };
+
+// The few words the host reads after a level go to pinned host memory in one tiny launch.  A large kernel that wrote them
+// itself would end with a system-scope release of everything it left dirty in L2.
+struct PublishArgs {
+    const u32* src[4];
+    u32* dst[4];
+    u32 words[4];
+};
+__global__ void publish_kernel(PublishArgs a) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (u32 q = threadIdx.x; q < a.words[k]; q += blockDim.x) a.dst[k][q] = a.src[k][q];
+}
 
 // how many samples keep each child of parent u (0 = the slot is not a union node)
 template <typename P>
@@ -528,16 +541,14 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
         const u32 nc = __popc(pres);
         o.firstchild[u] = v0;
         o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
-        if (!nc) continue;
+        if (!nc || v0 + nc > o.cap) continue;  // a level wider than its arrays is reported through the total, not written
         u32 mm = pres;
         for (u32 j = 0; j < nc; ++j) {
             const u32 c = (u32)__ffs(mm) - 1u;
             mm &= mm - 1;
             const u32 t = c == 0 ? nT4[pc][0] : (c == 1 ? nT4[pc][1] : (c == 2 ? nT4[pc][2] : nT4[pc][3]));
-            if (v0 + j < o.cap) {
-                o.slot[v0 + j] = 4u * u + c;
-                o.nT[v0 + j] = (u16)t;
-            }
+            o.slot[v0 + j] = 4u * u + c;
+            o.nT[v0 + j] = (u16)t;
         }
         for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
             const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
             for (u32 j = 0; j < nc; ++j) {
                 const u32 c = (u32)__ffs(m2) - 1u;
                 m2 &= m2 - 1;
-                if (v0 + j < o.cap) rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+                rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
             }
         }
     }
@@ -1333,6 +1344,7 @@ class Engine {
     u32 Rcap = 0;             // handles of a record buffer (Fcap plus the slack of the windowed allocation)
     u32 ns_shards = 1, region = 0;
     u32* h_alloc = nullptr;   // pinned [nlocal][ALLOC_SHARDS]
+    u32* d_pub_tot = nullptr; u32* d_pub_alloc = nullptr; u64* d_pub_cmax = nullptr;  // device side of what publish_kernel hands over
     std::vector<P*> rec[2];     // compact child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
     std::vector<u32*> tpos;     // handle of the first child record of every node of the level being expanded
@@ -1515,6 +1527,9 @@ class Engine {
         memset(h_alloc, 0, (size_t)nlocal * ALLOC_SHARDS * sizeof(u32));
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
+        if (int rc = dalloc(d_pub_tot, 8)) return rc;
+        if (int rc = dalloc(d_pub_alloc, (size_t)nlocal * ALLOC_SHARDS)) return rc;
+        if (int rc = dalloc(d_pub_cmax, (size_t)(world > 0 ? world : 1))) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 320 * sizeof(u32)));
         DSM_HIP(hipHostMalloc((void**)&h_childmax, (size_t)(world > 0 ? world : 1) * sizeof(u64)));
         size_t used = 0;
@@ -1750,7 +1765,7 @@ class Engine {
             ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
-            ao.h_totals = h_totals; ao.h_alloc = h_alloc; ao.h_childmax = h_childmax; ao.alloc = d_alloc;
+            ao.h_totals = d_pub_tot; ao.h_alloc = d_pub_alloc; ao.h_childmax = d_pub_cmax; ao.alloc = d_alloc;
             ao.rp = d_rp_tab[nxt];
             ao.tpos = d_tpos_tab;
             if (nb == 1) {
@@ -1767,6 +1782,17 @@ class Engine {
             // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
+            }
+            {
+                PublishArgs pa;
+                memset(&pa, 0, sizeof pa);
+                pa.src[0] = d_pub_tot; pa.dst[0] = h_totals; pa.words[0] = 1;
+                pa.src[1] = d_pub_alloc; pa.dst[1] = h_alloc; pa.words[1] = trie_mode ? 0u : (u32)nlocal * ALLOC_SHARDS;
+                pa.src[2] = reinterpret_cast<const u32*>(d_pub_cmax); pa.dst[2] = reinterpret_cast<u32*>(h_childmax); pa.words[2] = 2u * (u32)world;
+                if (filtered) {
+                    pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
+                }
+                hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, st, pa);
             }
             DSM_HIP(hipStreamSynchronize(st));
             const u32 Fn = h_totals[0];
@@ -1906,9 +1932,9 @@ class Engine {
                            me.cand_flag, one ? (u64*)nullptr : cand_key);
         u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         if (one) {
-            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), h_totals + 300, st);  // total lands in pinned host memory
+            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
         } else {
-            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, reinterpret_cast<u64*>(h_totals + 300), st);
+            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
         }
         return 0;
     }
