@@ -8,7 +8,7 @@ echo stats done
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc8_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $R/gpurun_out/bench_pmc_$n.log 2>&1 || echo "fail $n"
-  python3 $R/scratch/pmc_agg.py $R/gpurun_out/pmc8_$n >> $R/gpurun_out/pmc8_summary.txt
+  python3 $R/tools/profiling/pmc_agg.py $R/gpurun_out/pmc8_$n >> $R/gpurun_out/pmc8_summary.txt
   echo "pmc $n done"
 done
 find $R/gpurun_out/prof_r01h $R/gpurun_out/pmc8_* -name "*.csv" -size +1M -delete
