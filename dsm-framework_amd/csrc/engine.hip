@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -844,6 +845,14 @@ struct LevelDev {
     u32 npairs;
 };
 
+// offsets of the chunk boundaries (path bytes, pairs) for the host: out[2c], out[2c+1] for boundary tuple tb[c]
+constexpr int EMIT_MAX_CHUNKS = 8;
+struct ChunkBounds { u32 tb[EMIT_MAX_CHUNKS + 1]; int n; };
+__global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ path_off, const u32* __restrict__ pair_off, u32* __restrict__ out) {
+    const int c = threadIdx.x;
+    if (c <= cbs.n) { out[2 * c] = path_off[cbs.tb[c]]; out[2 * c + 1] = pair_off[cbs.tb[c]]; }
+}
+
 __global__ void tuple_size_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
                                   u32* __restrict__ plen, u32* __restrict__ npair) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,8 +866,8 @@ __global__ void tuple_size_kernel(u32 nt, const LevelDev* __restrict__ lv, const
 
 __global__ void tuple_fill_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
                                   const u32* __restrict__ path_off, const u32* __restrict__ pair_off, char* __restrict__ paths,
-                                  u32* __restrict__ ids, u64* __restrict__ freqs) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+                                  u32* __restrict__ ids, u64* __restrict__ freqs, u32 r0) {
+    u32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x;  // tuples [r0, nt)
     if (r >= nt) return;
     u32 lvl = t_level[r];
     const LevelDev L = lv[lvl];
@@ -1051,19 +1060,83 @@ struct DevGrow {  // device buffer that only grows
 struct EmitSet {
     DevGrow dev[5];  // same five arrays on the device: they outlive the arena while the copy stream drains them
     hipEvent_t ready = nullptr;  // recorded on the copy stream after the last device-to-host copy
+    // A large set travels in chunks of consecutive tuples: chunk c is filled, copied and handed to the sink while the
+    // following ones are still on their way (the tail of a prefix is one chunk of host work, not the whole set).
+    static constexpr int MAX_CHUNKS = EMIT_MAX_CHUNKS;
+    int nchunk = 1;
+    u32 cb[MAX_CHUNKS + 1] = {0};            // tuple boundaries
+    hipEvent_t cready[MAX_CHUNKS] = {nullptr};  // chunk c has landed in pinned memory
     int device = 0;
     PinBuf pin[5];   // path_off, pair_off, ids, freqs, paths (device order = post-order rank)
     RawBuf out[6];   // o_path, o_pair, ent, paths, ids, freqs (kept tuples only)
     RawBuf ent_all, keep;
     u32 nt = 0;
     bool busy = false;
-    ~EmitSet() { if (ready) (void)hipEventDestroy(ready); }
+    ~EmitSet() {
+        if (ready) (void)hipEventDestroy(ready);
+        for (auto e : cready) if (e) (void)hipEventDestroy(e);
+    }
 };
 
-static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
+// Persistent helpers of the emitter thread: a pass over a chunk is split into nth ranges; creating threads per pass would
+// put ~30 clone()/mmap() calls per prefix in competition with the HIP runtime's own address-space work.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::function<void(unsigned)> job;
+    unsigned gen = 0, pending = 0;
+    bool stop = false;
+    void ensure(unsigned n) {  // n - 1 workers, worker k runs range k + 1
+        while (th.size() + 1 < n) {
+            const unsigned id = (unsigned)th.size() + 1;
+            th.emplace_back([this, id] {
+                unsigned seen = 0;
+                for (;;) {
+                    std::function<void(unsigned)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        if (id >= active) { continue; }
+                        f = job;
+                    }
+                    f(id);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) done_cv.notify_all();
+                    }
+                }
+            });
+        }
+    }
+    unsigned active = 0;
+    void run(unsigned n, const std::function<void(unsigned)>& f) {  // f(0) .. f(n-1), f(0) on the caller
+        ensure(n);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f; active = n; pending = n - 1; ++gen;
+        }
+        cv.notify_all();
+        f(0u);
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
+static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    const u32 nt = E.nt;
+    const u32 nt = t_hi - t_lo;  // tuples [t_lo, t_hi) of the set
     const u32* path_off = (const u32*)E.pin[0].p;
     const u32* pair_off = (const u32*)E.pin[1].p;
     const u32* ids = (const u32*)E.pin[2].p;
@@ -1075,7 +1148,7 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
     if (nt < 65536) nth = 1;
     const u32 per = (nt + nth - 1) / nth;
     std::vector<u64> cnt_t(nth + 1, 0), cnt_p(nth + 1, 0), cnt_q(nth + 1, 0);
-    auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; };
+    auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; lo += t_lo; hi += t_lo; };
     const double* terms = term_table();
     const double* logn = logn_table();
     auto pass1 = [&](unsigned t) {
@@ -1091,19 +1164,14 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
                 sumNlogN += f < TERM_TAB ? terms[f] : (double)(f + 1) * log((double)(f + 1)) / LN2;
             }
             double e = (sumN < LOGN_TAB ? logn[sumN] : log((double)sumN) / LN2) - sumNlogN / (double)sumN;
-            ent[r] = e;
+            ent[r - t_lo] = e;
             bool k = !(emax > 0 && (e < emin || e > emax));
-            keep[r] = k;
+            keep[r - t_lo] = k;
             if (k) { ++kt; kp += path_off[r + 1] - path_off[r]; kq += pair_off[r + 1] - pair_off[r]; }
         }
         cnt_t[t + 1] = kt; cnt_p[t + 1] = kp; cnt_q[t + 1] = kq;
     };
-    auto run_all = [&](auto&& fn) {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nth; ++t) th.emplace_back(fn, t);
-        fn(0u);
-        for (auto& x : th) x.join();
-    };
+    auto run_all = [&](auto&& fn) { pool.run(nth, fn); };
     run_all(pass1);
     for (unsigned t = 0; t < nth; ++t) { cnt_t[t + 1] += cnt_t[t]; cnt_p[t + 1] += cnt_p[t]; cnt_q[t + 1] += cnt_q[t]; }
     const u64 W = cnt_t[nth], PW = cnt_p[nth], QW = cnt_q[nth];
@@ -1118,9 +1186,9 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
         range(t, lo, hi);
         u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
         for (u32 r = lo; r < hi; ++r) {
-            if (!keep[r]) continue;
+            if (!keep[r - t_lo]) continue;
             u32 pb = path_off[r], pl = path_off[r + 1] - pb, qb = pair_off[r], ql = pair_off[r + 1] - qb;
-            o_path[w] = (u32)pw; o_pair[w] = (u32)qw; o_ent[w] = ent[r];
+            o_path[w] = (u32)pw; o_pair[w] = (u32)qw; o_ent[w] = ent[r - t_lo];
             memcpy(o_paths + pw, paths + pb, pl);
             memcpy(o_ids + qw, ids + qb, (size_t)ql * 4);
             memcpy(o_freqs + qw, freqs + qb, (size_t)ql * 8);
@@ -1146,6 +1214,7 @@ static int emit_job(EmitSet& E, u32 d, double emin, double emax, dsm_tuple_sink 
 // Host worker: emits prefix k while the GPU already expands prefix k+1 (two pinned sets).
 struct Emitter {
     EmitSet set[2];
+    HostPool pool;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -1173,8 +1242,11 @@ struct Emitter {
             u64 t = 0, pq = 0;
             double m = 0;
             (void)hipSetDevice(set[k].device);
-            int rc = set[k].ready && hipEventSynchronize(set[k].ready) != hipSuccess ? 1 : 0;  // copies of this set have landed
-            if (!rc) rc = emit_job(set[k], d, emin, emax, sink, ctx, &t, &pq, &m);
+            int rc = 0;
+            for (int c = 0; c < set[k].nchunk && !rc; ++c) {
+                rc = set[k].cready[c] && hipEventSynchronize(set[k].cready[c]) != hipSuccess ? 1 : 0;  // the chunk has landed
+                if (!rc && set[k].cb[c + 1] > set[k].cb[c]) rc = emit_job(pool, set[k], set[k].cb[c], set[k].cb[c + 1], d, emin, emax, sink, ctx, &t, &pq, &m);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 tuples += t; pairs += pq; ms += m;
@@ -1387,6 +1459,7 @@ class Engine {
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (fill_done) (void)hipEventDestroy(fill_done);
+        for (auto e : chunk_filled) if (e) (void)hipEventDestroy(e);
     }
 
     template <class T> int dalloc(T*& p, size_t n) {
@@ -2012,7 +2085,6 @@ class Engine {
         E.device = device;
         if (!E.ready) DSM_HIP(hipEventCreateWithFlags(&E.ready, hipEventDisableTiming));
         if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        if (!fill_done) DSM_HIP(hipEventCreateWithFlags(&fill_done, hipEventDisableTiming));
         u32 *plen, *npair;
         EARENA_GET(plen, u32, nt);
         EARENA_GET(npair, u32, nt);
@@ -2027,6 +2099,14 @@ class Engine {
         exclusive_scan<u32, u32>(npair, pair_off, nt, stmp, d_totals + 1, st);
         DSM_HIP(hipMemcpyAsync(path_off + nt, d_totals, sizeof(u32), hipMemcpyDeviceToDevice, st));
         DSM_HIP(hipMemcpyAsync(pair_off + nt, d_totals + 1, sizeof(u32), hipMemcpyDeviceToDevice, st));
+        // chunk boundaries: consecutive tuple ranges of at least a million tuples
+        ChunkBounds cbs;
+        cbs.n = nt >= (4u << 20) ? 4 : (nt >= (2u << 20) ? 2 : 1);
+        for (int c = 0; c <= cbs.n; ++c) cbs.tb[c] = (u32)((u64)nt * c / cbs.n);
+        u32* d_bounds;
+        EARENA_GET(d_bounds, u32, 2 * (EmitSet::MAX_CHUNKS + 1));
+        hipLaunchKernelGGL(chunk_bounds_kernel, dim3(1), dim3(64), 0, st, cbs, path_off, pair_off, d_bounds);  // after the two sentinel copies
+        DSM_HIP(hipMemcpyAsync(h_totals + 16, d_bounds, 2 * (cbs.n + 1) * sizeof(u32), hipMemcpyDeviceToHost, st));
         DSM_HIP(hipMemcpyAsync(h_totals, d_totals, 2 * sizeof(u32), hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
         const u64 path_bytes = h_totals[0], npairs = h_totals[1];
@@ -2036,20 +2116,34 @@ class Engine {
         u32* d_ids = (u32*)E.dev[2].p;
         u64* d_freqs = (u64*)E.dev[3].p;
         char* d_paths = (char*)E.dev[4].p;
-        hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs);
-        DSM_HIP(hipGetLastError());
-        DSM_HIP(hipEventRecord(fill_done, st));
         if (int rc = E.pin[0].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.pin[1].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.pin[2].ensure((size_t)npairs * 4)) return rc;
         if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
         if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
-        DSM_HIP(hipStreamWaitEvent(copy_stream, fill_done, 0));
-        DSM_HIP(hipMemcpyAsync(E.pin[0].p, path_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
-        DSM_HIP(hipMemcpyAsync(E.pin[1].p, pair_off, ((size_t)nt + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
-        DSM_HIP(hipMemcpyAsync(E.pin[2].p, d_ids, npairs * 4, hipMemcpyDeviceToHost, copy_stream));
-        DSM_HIP(hipMemcpyAsync(E.pin[3].p, d_freqs, npairs * 8, hipMemcpyDeviceToHost, copy_stream));
-        DSM_HIP(hipMemcpyAsync(E.pin[4].p, d_paths, path_bytes, hipMemcpyDeviceToHost, copy_stream));
+        E.nchunk = cbs.n;
+        for (int c = 0; c < cbs.n; ++c) {  // fill, copy and signal chunk by chunk
+            const u32 t0 = cbs.tb[c], t1 = cbs.tb[c + 1];
+            E.cb[c] = t0; E.cb[c + 1] = t1;
+            if (!E.cready[c]) DSM_HIP(hipEventCreateWithFlags(&E.cready[c], hipEventDisableTiming));
+            if (!chunk_filled[c]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[c], hipEventDisableTiming));
+            if (t1 > t0) {
+                hipLaunchKernelGGL(tuple_fill_kernel, grid_for(t1 - t0), dim3(256), 0, st, t1, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs, t0);
+                DSM_HIP(hipGetLastError());
+            }
+            DSM_HIP(hipEventRecord(chunk_filled[c], st));
+            DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
+            const u64 pb0 = h_totals[16 + 2 * c], qb0 = h_totals[17 + 2 * c], pb1 = h_totals[16 + 2 * (c + 1)], qb1 = h_totals[17 + 2 * (c + 1)];
+            // boundary entries are shared by neighbouring chunks: both copy the same value
+            DSM_HIP(hipMemcpyAsync((u32*)E.pin[0].p + t0, path_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+            DSM_HIP(hipMemcpyAsync((u32*)E.pin[1].p + t0, pair_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+            if (qb1 > qb0) {
+                DSM_HIP(hipMemcpyAsync((u32*)E.pin[2].p + qb0, d_ids + qb0, (qb1 - qb0) * 4, hipMemcpyDeviceToHost, copy_stream));
+                DSM_HIP(hipMemcpyAsync((u64*)E.pin[3].p + qb0, d_freqs + qb0, (qb1 - qb0) * 8, hipMemcpyDeviceToHost, copy_stream));
+            }
+            if (pb1 > pb0) DSM_HIP(hipMemcpyAsync((char*)E.pin[4].p + pb0, d_paths + pb0, pb1 - pb0, hipMemcpyDeviceToHost, copy_stream));
+            DSM_HIP(hipEventRecord(E.cready[c], copy_stream));
+        }
         DSM_HIP(hipEventRecord(E.ready, copy_stream));
         E.nt = nt;
         emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
@@ -2058,6 +2152,7 @@ class Engine {
     }
     hipStream_t copy_stream = nullptr;
     hipEvent_t fill_done = nullptr;
+    hipEvent_t chunk_filled[EmitSet::MAX_CHUNKS] = {nullptr};
 
     // wait for the emitter and fold its counters into stats
     int finish_emits() {
