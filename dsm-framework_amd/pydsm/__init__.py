@@ -108,6 +108,13 @@ def lib():
         L.dsm_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.dsm_free.argtypes = [C.c_void_p]
+        L.dsm_distmat_create.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.dsm_distmat_destroy.argtypes = [C.c_void_p]
+        L.dsm_distmat_steps.argtypes = [C.c_double, C.c_void_p, C.c_int]
+        L.dsm_distmat_add.argtypes = [C.c_void_p, C.POINTER(TupleBatch)]
+        L.dsm_distmat_add_text.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.dsm_distmat_finish.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.dsm_distmat_format.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.POINTER(C.c_void_p)]
         _lib = L
     return _lib
 
@@ -350,3 +357,61 @@ def merge(tries, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0,
     st = Stats()
     _check(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)))
     return (b"".join(out) if text else None), st
+
+
+class DistMat:
+    """Distance matrices of a tuple stream (wrapper-distance-matrix/smtxt2entropy.c), accumulated on the GPU.
+    add(batch) takes the batches a tuple sink receives (use as on_batch=dm.add), add_text() takes metaserver output lines."""
+
+    def __init__(self, samples, maxent=None, entstep=None, minfreq=0, device=0):
+        if (maxent is None) == (entstep is None):
+            raise ValueError("give either maxent (list) or entstep")
+        if entstep is not None:
+            buf = (C.c_double * 1024)()
+            n = lib().dsm_distmat_steps(float(entstep), buf, 1024)
+            if n < 0:
+                _check(n)
+            maxent = list(buf[:n])
+        self.samples, self.nm = int(samples), len(maxent)
+        me = (C.c_double * self.nm)(*maxent)
+        self.h = C.c_void_p()
+        _check(lib().dsm_distmat_create(device, self.samples, me, self.nm, minfreq, C.byref(self.h)))
+
+    def add(self, batch):
+        _check(lib().dsm_distmat_add(self.h, C.byref(batch)))
+
+    def add_text(self, text):
+        _check(lib().dsm_distmat_add_text(self.h, text, len(text)))
+
+    def finish(self):
+        """-> dict(maxent, noutput, count, log, sqrt, lgamma): cumulative matrices in the tool's print order."""
+        nm, s = self.nm, self.samples
+        me = np.zeros(nm, np.float64)
+        nout = np.zeros(nm, np.uint32)
+        cnt = np.zeros((nm, s, s), np.uint32)
+        mats = [np.zeros((nm, s, s), np.float64) for _ in range(3)]
+        _check(lib().dsm_distmat_finish(self.h, me.ctypes.data, nout.ctypes.data, cnt.ctypes.data, *[m.ctypes.data for m in mats]))
+        return dict(maxent=me, noutput=nout, count=cnt, log=mats[0], sqrt=mats[1], lgamma=mats[2])
+
+    @staticmethod
+    def format(res):
+        """The tool's four output files (count, log, sqrt, lgamma) as bytes."""
+        nm, s = res["count"].shape[0], res["count"].shape[1]
+        texts = (C.c_void_p * 4)()
+        arrs = [np.ascontiguousarray(res[k]) for k in ("maxent", "noutput", "count", "log", "sqrt", "lgamma")]
+        _check(lib().dsm_distmat_format(s, nm, *[a.ctypes.data for a in arrs], texts))
+        out = [C.string_at(t) for t in texts]
+        for t in texts:
+            lib().dsm_free(t)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().dsm_distmat_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

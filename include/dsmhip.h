@@ -203,6 +203,32 @@ void dsm_miner_destroy(dsm_miner* m);
 int dsm_format_batch(const dsm_tuple_batch* batch, char** text, size_t* len);
 void dsm_free(void* p);
 
+/* ------------------------------------------------------------------------------------------------
+ * Distance matrices of the tuple stream: the accumulation of wrapper-distance-matrix/smtxt2entropy.c
+ * (default mode: no -S sample file, no -N normalisation) on the GPU.
+ *   per tuple: normalised entropy (smtxt2entropy.c:128-145, evaluated on the host with the reference's expression
+ *   and libm so that the bucket choice of :690-703 is exact), then for the chosen <max_entropy> bucket the pair
+ *   counts and the three squared-distance sums of add() (:167-197) -- accumulated on the device.
+ * The matrices returned by dsm_distmat_finish are cumulative exactly as the tool prints them (:722-752, :230-242).
+ * The double sums add the same terms in a different order than the tool (tolerance: 1e-9 relative; counts exact).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dsm_distmat dsm_distmat;
+int dsm_distmat_create(int device, uint32_t samples, const double* maxent, uint32_t nmaxent, uint32_t minfreq, dsm_distmat** out);
+void dsm_distmat_destroy(dsm_distmat* m);
+/* -e,--entstep list of the tool (smtxt2entropy.c:258-285); returns the number of values written (<= cap) or < 0 */
+int dsm_distmat_steps(double step, double* out, int cap);
+/* a batch exactly as a dsm_tuple_sink receives it (paths and the entropy column are not used) */
+int dsm_distmat_add(dsm_distmat* m, const dsm_tuple_batch* batch);
+/* metaserver output lines "path entropy id:freq ...\n" (smtxt2entropy.c:84-125,656-680) */
+int dsm_distmat_add_text(dsm_distmat* m, const char* text, size_t len);
+/* maxent_sorted[nmaxent] (descending, the tool's matrix order), noutput[nmaxent], and four [nmaxent][samples][samples]
+ * arrays; any pointer may be NULL.  May be called once. */
+int dsm_distmat_finish(dsm_distmat* m, double* maxent_sorted, uint32_t* noutput, uint32_t* count, double* mlog, double* msqrt,
+                       double* mlgamma);
+/* the tool's four output files (count, log, sqrt, lgamma) as text; each malloc'd, release with dsm_free */
+int dsm_distmat_format(uint32_t samples, uint32_t nmaxent, const double* maxent_sorted, const uint32_t* noutput, const uint32_t* count,
+                       const double* mlog, const double* msqrt, const double* mlgamma, char* text[4]);
+
 #ifdef __cplusplus
 }
 #endif

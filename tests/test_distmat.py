@@ -76,3 +76,80 @@ def test_oracle_reproduces_reference_tool_output(setname, case):
         want = gzip.open(os.path.join(GOLD, setname, "distmat.%s.%s.gz" % (case, kind)), "rb").read()
         assert got == want, (setname, case, kind)
     assert nout.max() <= text.count(b"\n")
+
+
+@pytest.fixture(scope="module")
+def pydsm_mod():
+    import pydsm
+    pydsm.lib()
+    return pydsm
+
+
+def _cmp(res, nout, cnt, mats):
+    assert (res["noutput"] == nout).all()
+    assert (res["count"] == cnt).all()
+    for k, want in zip(("log", "sqrt", "lgamma"), mats):
+        got = res[k]
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-6), (k, np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname,case", CASES)
+def test_gpu_distmat_matches_oracle_on_goldens(setname, case, pydsm_mod):
+    text, smpls, maxent, minfreq = case_input(setname, case)
+    texts, nout, cnt, mats = oracle_run(text, smpls, maxent, minfreq)
+    with pydsm_mod.DistMat(smpls, maxent=maxent, minfreq=minfreq) as dm:
+        half = text.rfind(b"\n", 0, len(text) // 2) + 1
+        dm.add_text(text[:half])          # two batches: accumulation across calls
+        dm.add_text(text[half:])
+        res = dm.finish()
+    _cmp(res, nout, cnt, mats)
+    got = pydsm_mod.DistMat.format(res)
+    assert got[0] == texts[0]             # the count file is exact
+    for g, w in zip(got[1:], texts[1:]):  # the double files agree line for line up to the last printed digits
+        assert g.count(b"\n") == w.count(b"\n")
+        for a, b in zip(g.split(), w.split()):
+            if a != b:
+                assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b))) + 2e-6, (a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_distmat_fused_with_mining_and_many_samples(golden, pydsm_mod):
+    """Tuples go from the miner's sink straight into the accumulator (no text round trip); 30 samples use the global-atomic
+    path (the matrices do not fit LDS)."""
+    for setname, prefixes, kw, maxent in (("five", ["A", "C", "G", "T"], dict(fmin=10, emax=2.0), [0.4, 0.8, 1.0]),
+                                         ("many30", ["AC", "G"], dict(fmin=3, maxdepth=14, emax=5.0), [0.7, 0.9, 1.0])):
+        names = golden.manifest["sets"][setname]["names"]
+        idx = [pydsm_mod.Index(golden.fmi(setname, n)) for n in names]
+        with pydsm_mod.DistMat(len(names), maxent=maxent) as dm, pydsm_mod.Miner(idx, **kw) as m:
+            text, st = m.mine_many(prefixes, on_batch=dm.add)
+            res = dm.finish()
+        texts, nout, cnt, mats = oracle_run(text, len(names), maxent, 0)
+        _cmp(res, nout, cnt, mats)
+        assert int(res["noutput"][0]) <= st.tuples
+        for ix in idx:
+            ix.close()
+
+
+@pytest.mark.gpu
+def test_gpu_distmat_large_frequencies_and_errors(pydsm_mod):
+    rng = np.random.default_rng(5)
+    lines = []
+    for _ in range(20000):
+        k = int(rng.integers(1, 7))
+        ids = rng.choice(6, k, replace=False)
+        fr = [int(x) for x in np.where(rng.random(k) < 0.02, rng.integers(100000, 3000000, k), rng.integers(1, 400, k))]
+        lines.append("ACGT 0.5 " + " ".join("%d:%d" % (i, f) for i, f in zip(ids, fr)))
+    text = ("\n".join(lines) + "\n").encode()
+    maxent = [0.2, 0.5, 0.9, 1.0]
+    texts, nout, cnt, mats = oracle_run(text, 6, maxent, 3)
+    with pydsm_mod.DistMat(6, maxent=maxent, minfreq=3) as dm:
+        dm.add_text(text)
+        _cmp(dm.finish(), nout, cnt, mats)
+    with pytest.raises(pydsm_mod.DsmError):
+        pydsm_mod.DistMat(1, maxent=[1.0])
+    with pytest.raises(pydsm_mod.DsmError):
+        pydsm_mod.DistMat(4, maxent=[1.5])
+    with pydsm_mod.DistMat(3, maxent=[1.0]) as dm:
+        with pytest.raises(pydsm_mod.DsmError):
+            dm.add_text(b"ACG 0.1 7:3\n")          # sample id out of range
