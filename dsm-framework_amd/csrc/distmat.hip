@@ -202,48 +202,82 @@ static int dm_accumulate(dsm_distmat* m, size_t nt, const u32* pair_off, const u
     if (nt == 0) return DSM_OK;
     if (nt > 0xFFFFFFF0ull) return fail(DSM_E_INVAL, "dsm_distmat_add: batch too large");
     const u32 s = m->s, nm = m->nm;
-    std::vector<u32> o_off(nt + 1), o_ids, o_fr;
+    // host pass in parallel over tuple ranges: every worker cleans its tuples (minfreq, duplicates, sorted ids) into its own
+    // vectors and picks the buckets; the pieces are concatenated afterwards
+    unsigned nth = std::thread::hardware_concurrency();
+    if (const char* e = getenv("DSM_HOST_THREADS")) nth = (unsigned)atoi(e);
+    if (nth > 16) nth = 16;
+    if (nth < 1 || nt < 65536) nth = 1;
+    struct Piece { std::vector<u32> off, ids, fr; std::vector<u32> nout; int err = 0; };
+    std::vector<Piece> pc(nth);
     std::vector<signed char> bucket(nt);
-    o_ids.reserve(pair_off[nt]);
-    o_fr.reserve(pair_off[nt]);
-    std::vector<u32> fq(s, 0), seen;
-    for (size_t t = 0; t < nt; ++t) {
-        o_off[t] = (u32)o_ids.size();
-        seen.clear();
-        for (u32 q = pair_off[t]; q < pair_off[t + 1]; ++q) {
-            const u32 run = ids[q];
-            const unsigned frq = (unsigned)freqs[q];  // the tool reads frequencies with atoi into unsigned
-            if (run >= s) return fail(DSM_E_INVAL, "dsm_distmat: sample id out of range (smtxt2entropy.c:96-101)");
-            if (frq < m->minfreq) continue;
-            bool dup = false;
-            for (u32 x : seen) dup |= x == run;
-            if (!dup) seen.push_back(run);
-            fq[run] = frq;
+    const double LOG2 = log(2), LOGS = log((int)s);
+    auto work = [&](unsigned w) {
+        const size_t lo = nt * w / nth, hi = nt * (w + 1) / nth;
+        Piece& P = pc[w];
+        P.nout.assign(nm, 0);
+        P.off.reserve(hi - lo + 1);
+        P.ids.reserve(pair_off[hi] - pair_off[lo]);
+        P.fr.reserve(pair_off[hi] - pair_off[lo]);
+        std::vector<u32> fq(s, 0), seen;
+        for (size_t t = lo; t < hi; ++t) {
+            P.off.push_back((u32)P.ids.size());
+            seen.clear();
+            for (u32 q = pair_off[t]; q < pair_off[t + 1]; ++q) {
+                const u32 run = ids[q];
+                const unsigned frq = (unsigned)freqs[q];  // the tool reads frequencies with atoi into unsigned
+                if (run >= s) { P.err = 1; return; }
+                if (frq < m->minfreq) continue;
+                bool dup = false;
+                for (u32 x : seen) dup |= x == run;
+                if (!dup) seen.push_back(run);
+                fq[run] = frq;
+            }
+            std::sort(seen.begin(), seen.end());
+            // entropy(), smtxt2entropy.c:128-145: unsigned 32-bit sumN, term-by-term log(x)/log(2)
+            unsigned sumN = s;
+            double sumNlogN = 0;
+            for (u32 x : seen) {
+                const unsigned frq = fq[x];
+                sumN += frq;
+                sumNlogN += (double)(frq + 1) * log(frq + 1) / LOG2;
+            }
+            const double entropy = (log(sumN) / LOG2 - sumNlogN / (double)sumN);
+            const double entr = LOG2 * entropy / LOGS;
+            int b = -1;
+            for (int i = (int)nm; i > 0;) {
+                --i;
+                if (entr <= m->maxent[i]) { b = i; break; }
+            }
+            bucket[t] = (signed char)b;
+            if (b >= 0) {
+                ++P.nout[b];
+                for (u32 x : seen) { P.ids.push_back(x); P.fr.push_back(fq[x]); }
+            }
+            for (u32 x : seen) fq[x] = 0;
         }
-        std::sort(seen.begin(), seen.end());
-        // entropy(), smtxt2entropy.c:128-145: unsigned 32-bit sumN, term-by-term log(x)/log(2)
-        unsigned sumN = s;
-        double sumNlogN = 0;
-        for (u32 x : seen) {
-            const unsigned frq = fq[x];
-            sumN += frq;
-            sumNlogN += (double)(frq + 1) * log(frq + 1) / log(2);
-        }
-        const double entropy = (log(sumN) / log(2) - sumNlogN / (double)sumN);
-        const double entr = log(2) * entropy / log((int)s);
-        int b = -1;
-        for (int i = (int)nm; i > 0;) {
-            --i;
-            if (entr <= m->maxent[i]) { b = i; break; }
-        }
-        bucket[t] = (signed char)b;
-        if (b >= 0) {
-            ++m->noutput[b];
-            for (u32 x : seen) { o_ids.push_back(x); o_fr.push_back(fq[x]); }
-        }
-        for (u32 x : seen) fq[x] = 0;
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned w = 1; w < nth; ++w) th.emplace_back(work, w);
+        work(0);
+        for (auto& t : th) t.join();
     }
-    o_off[nt] = (u32)o_ids.size();
+    std::vector<u32> o_off(nt + 1), o_ids, o_fr;
+    {
+        size_t tot = 0;
+        for (auto& P : pc) { if (P.err) return fail(DSM_E_INVAL, "dsm_distmat: sample id out of range (smtxt2entropy.c:96-101)"); tot += P.ids.size(); }
+        o_ids.reserve(tot); o_fr.reserve(tot);
+        size_t t = 0;
+        for (unsigned w = 0; w < nth; ++w) {
+            const u32 base = (u32)o_ids.size();
+            for (u32 v : pc[w].off) o_off[t++] = base + v;
+            o_ids.insert(o_ids.end(), pc[w].ids.begin(), pc[w].ids.end());
+            o_fr.insert(o_fr.end(), pc[w].fr.begin(), pc[w].fr.end());
+            for (u32 i = 0; i < nm; ++i) m->noutput[i] += pc[w].nout[i];
+        }
+        o_off[nt] = (u32)o_ids.size();
+    }
     DM_HIP(hipSetDevice(m->device));
     const size_t np = o_ids.size();
     if (nt + 1 > m->cap_t) {

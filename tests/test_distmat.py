@@ -153,3 +153,31 @@ def test_gpu_distmat_large_frequencies_and_errors(pydsm_mod):
     with pydsm_mod.DistMat(3, maxent=[1.0]) as dm:
         with pytest.raises(pydsm_mod.DsmError):
             dm.add_text(b"ACG 0.1 7:3\n")          # sample id out of range
+
+
+@pytest.mark.gpu
+def test_cli_dropin_writes_the_tools_files(tmp_path):
+    """smtxt2entropy_hip with the reference's options: the count file is byte-identical to the reference tool's, the double
+    files agree to the printed precision; an existing output file is refused like the tool does."""
+    exe = os.path.join(ROOT, "dsm-framework_amd", "host", "smtxt2entropy_hip")
+    text, smpls, maxent, minfreq = case_input("five", "minfreq")
+    args = [exe, "-s", str(smpls), "-m", ",".join(str(x) for x in maxent), "-M", str(minfreq), "-F", "o"]
+    r = subprocess.run(args, input=text, cwd=tmp_path, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    for kind in ("count", "log", "sqrt", "lgamma"):
+        got = open(os.path.join(tmp_path, kind + ".o"), "rb").read()
+        want = gzip.open(os.path.join(GOLD, "five", "distmat.minfreq.%s.gz" % kind), "rb").read()
+        if kind == "count":
+            assert got == want
+        else:
+            assert len(got.split()) == len(want.split())
+            for a, b in zip(got.split(), want.split()):
+                if a != b:
+                    assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b))) + 2e-6, (kind, a, b)
+    r = subprocess.run(args, input=text, cwd=tmp_path, capture_output=True)
+    assert r.returncode == 1 and b"already exists" in r.stderr
+    # -e steps
+    text, smpls, maxent, _ = case_input("toy3", "step")
+    r = subprocess.run([exe, "-s", str(smpls), "-e", "0.3", "-F", "s"], input=text, cwd=tmp_path, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(tmp_path, "count.s"), "rb").read() == gzip.open(os.path.join(GOLD, "toy3", "distmat.step.count.gz"), "rb").read()
