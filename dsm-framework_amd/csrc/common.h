@@ -88,6 +88,9 @@ struct dsm_index {
     void* d_rare;
     void* d_wt_nodes;
     void* d_wt_blob;
+    // residency (dsm_index_offload / dsm_index_reload): the blocks' pinned host copy, made on the first offload
+    void* h_blk = nullptr;
+    dsm::u64 blk_bytes = 0;
 };
 
 namespace dsm {

@@ -1683,6 +1683,8 @@ class Engine {
             if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
                 return fail(DSM_E_INVAL, "prefix must be over A,C,G,T");  // anything else has an empty LF interval: nothing to send
         DSM_HIP(hipSetDevice(device));
+        for (int s_ = 0; s_ < nlocal && !trie_mode; ++s_)
+            if (!idx[s_]->dev.blk) return fail(DSM_E_INVAL, "an index of this miner is offloaded: dsm_index_reload first");
         arena.off = 0;
         earena.off = 0;
         bool emitting = emit;       // cleared when this rank's emission side runs out of memory in a multi-rank run

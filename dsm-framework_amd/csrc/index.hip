@@ -411,6 +411,7 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
     ix->device = device;
     ix->name = libname(path);
     ix->device_bytes = nblk * sizeof(Blk) + nsb * 32 + nrare * 32;
+    ix->blk_bytes = nblk * sizeof(Blk);
     dv.blk = d_blk.p; dv.sbase = d_sbase.p; dv.rare = d_rare.p;
     ix->d_blk = d_blk.release();
     ix->d_sbase = d_sbase.release();
@@ -441,6 +442,7 @@ struct TmpDev {
 static int lf_dev(const dsm_index* idx, const u8* d_c, const u64* d_i, u64* d_out, size_t k, unsigned layout, hipStream_t st) {
     if (!idx || (k && (!d_c || !d_i || !d_out))) return fail(DSM_E_INVAL, "dsm_lf_batch: null argument");
     if (k == 0) return DSM_OK;
+    if (!idx->dev.blk) return fail(DSM_E_INVAL, "the index is offloaded: dsm_index_reload first");
     if (k >= (1ull << 32) - 256) return fail(DSM_E_INVAL, "dsm_lf_batch: at most 2^32 - 257 queries per call");
     DSM_HIP(hipSetDevice(idx->device));
     TmpDev tmp;
@@ -483,7 +485,9 @@ int dsm_index_open_ex(const char* p, int device, unsigned flags, dsm_index** out
 void dsm_index_close(dsm_index* ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk); hipFree(ix->d_sbase); hipFree(ix->d_rare);
+    if (ix->d_blk) hipFree(ix->d_blk);
+    hipFree(ix->d_sbase); hipFree(ix->d_rare);
+    if (ix->h_blk) (void)hipHostFree(ix->h_blk);
     if (ix->d_wt_nodes) hipFree(ix->d_wt_nodes);
     if (ix->d_wt_blob) hipFree(ix->d_wt_blob);
     delete ix;
@@ -497,7 +501,38 @@ int dsm_index_meta(const dsm_index* ix, uint64_t C[256], dsm_code codes[256]) {
 }
 const char* dsm_index_name(const dsm_index* ix) { return ix ? ix->name.c_str() : ""; }
 int dsm_index_device(const dsm_index* ix) { return ix ? ix->device : -1; }
-uint64_t dsm_index_device_bytes(const dsm_index* ix) { return ix ? ix->device_bytes : 0; }
+uint64_t dsm_index_device_bytes(const dsm_index* ix) { return ix ? (ix->d_blk ? ix->device_bytes : ix->device_bytes - ix->blk_bytes) : 0; }
+
+// Residency: an index that is not needed for a while gives its blocks' HBM back and keeps them in pinned
+// host memory; reloading is one asynchronous host-to-device copy (the index is immutable, so the pinned copy is made once).
+int dsm_index_resident(const dsm_index* ix) { return ix && ix->d_blk ? 1 : 0; }
+int dsm_index_offload(dsm_index* ix) {
+    if (!ix) return fail(DSM_E_INVAL, "null index");
+    if (!ix->d_blk) return DSM_OK;
+    if (ix->d_wt_blob) return fail(DSM_E_UNSUPPORTED, "an index opened with DSM_OPEN_KEEP_WT cannot be offloaded");
+    DSM_HIP(hipSetDevice(ix->device));
+    if (!ix->h_blk) {
+        DSM_HIP(hipHostMalloc(&ix->h_blk, ix->blk_bytes));
+        DSM_HIP(hipMemcpy(ix->h_blk, ix->d_blk, ix->blk_bytes, hipMemcpyDeviceToHost));
+    }
+    DSM_HIP(hipDeviceSynchronize());  // nothing may still read the blocks
+    DSM_HIP(hipFree(ix->d_blk));
+    ix->d_blk = nullptr;
+    ix->dev.blk = nullptr;
+    return DSM_OK;
+}
+int dsm_index_reload(dsm_index* ix, void* stream) {
+    if (!ix) return fail(DSM_E_INVAL, "null index");
+    if (ix->d_blk) return DSM_OK;
+    DSM_HIP(hipSetDevice(ix->device));
+    void* p = nullptr;
+    if (hipMalloc(&p, ix->blk_bytes) != hipSuccess) return fail(DSM_E_NOMEM, "dsm_index_reload: hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(p, ix->h_blk, ix->blk_bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(DSM_E_HIP, std::string("dsm_index_reload: ") + hipGetErrorString(e)); }
+    ix->d_blk = p;
+    ix->dev.blk = (const Blk*)p;  // work queued on `stream` after this call sees the blocks; other streams must wait for it
+    return DSM_OK;
+}
 
 int dsm_lf_batch_dev(const dsm_index* ix, const uint8_t* c, const uint64_t* i, uint64_t* out, size_t k, unsigned layout, void* stream) {
     return lf_dev(ix, c, i, out, k, layout, (hipStream_t)stream);
@@ -524,6 +559,7 @@ int dsm_lf_batch(const dsm_index* ix, const uint8_t* c, const uint64_t* i, uint6
 int dsm_getl_batch(const dsm_index* ix, const uint64_t* i, uint8_t* out, size_t k, void* stream) {
     if (!ix || (k && (!i || !out))) return fail(DSM_E_INVAL, "dsm_getl_batch: null argument");
     if (k == 0) return DSM_OK;
+    if (!ix->dev.blk) return fail(DSM_E_INVAL, "the index is offloaded: dsm_index_reload first");
     DSM_HIP(hipSetDevice(ix->device));
     TmpDev tmp;
     u64* di = tmp.get<u64>(k);

@@ -108,6 +108,9 @@ def lib():
         L.dsm_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.dsm_free.argtypes = [C.c_void_p]
+        L.dsm_index_offload.argtypes = [C.c_void_p]
+        L.dsm_index_reload.argtypes = [C.c_void_p, C.c_void_p]
+        L.dsm_index_resident.argtypes = [C.c_void_p]
         L.dsm_distmat_create.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.dsm_distmat_destroy.argtypes = [C.c_void_p]
         L.dsm_distmat_steps.argtypes = [C.c_double, C.c_void_p, C.c_int]
@@ -153,6 +156,17 @@ class Index:
 
     def device_bytes(self):
         return lib().dsm_index_device_bytes(self.h)
+
+    def offload(self):
+        """Give the blocks' HBM back; they stay in pinned host memory (dsm_index_offload)."""
+        _check(lib().dsm_index_offload(self.h))
+
+    def reload(self, stream=None):
+        _check(lib().dsm_index_reload(self.h, stream))
+
+    @property
+    def resident(self):
+        return bool(lib().dsm_index_resident(self.h))
 
     def lf_batch(self, c, i):
         """LF(c[k], i[k]) for host arrays (FMIndex.h:84-90)."""

@@ -69,6 +69,14 @@ const char* dsm_index_name(const dsm_index* idx);
 int dsm_index_device(const dsm_index* idx);
 /* bytes of HBM held by the handle */
 uint64_t dsm_index_device_bytes(const dsm_index* idx);
+/* Residency (BASELINE configs[4]: more indexes than should stay in HBM).  dsm_index_offload gives the index blocks'
+ * HBM back and keeps them in pinned host memory (the copy is made once: an index is immutable); queries and miners
+ * fail with DSM_E_INVAL until dsm_index_reload, which allocates HBM again and queues ONE asynchronous host-to-device
+ * copy on `stream` (work queued on that stream afterwards sees the index; other streams must wait for it).
+ * The caller makes sure no query or miner is running on the index while it is offloaded or reloaded. */
+int dsm_index_offload(dsm_index* idx);
+int dsm_index_reload(dsm_index* idx, void* stream);
+int dsm_index_resident(const dsm_index* idx);
 
 /* LF(c,i) = C[c] + rank_c(BWT, i) -- TextCollection::LF, FMIndex.h:84-90 (HuffWT::rank HuffWT.h:66-83,
  * BitRank::rank BitRank.cpp:191-195).  i = UINT64_MAX is legal (rank(-1) = 0).  Host pointers. */

@@ -177,3 +177,18 @@ def test_positions_beyond_2_32():
                 owire, _ = o.enumerate(ix.name, p, fmin=10)
                 assert wire == owire, p
     o.close()
+
+
+def test_reload_time_of_a_full_size_index(big):
+    """f4 measurement: bringing the 1 GB block array of the configs[1] index back from pinned host memory."""
+    import time
+    import torch
+    pydsm, ix, path, reads = big
+    ix.offload()
+    t0 = time.time()
+    ix.reload()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print("reload of %.2f GB: %.1f ms = %.1f GB/s" % (ix.device_bytes() / 1e9, dt * 1e3, ix.device_bytes() / dt / 1e9))
+    assert ix.check() == ix.n
+    assert dt < 2.0

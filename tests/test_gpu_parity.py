@@ -310,3 +310,38 @@ def test_older_fmi_versions_and_degenerate_alphabets(golden, pydsm_mod, tmp_path
         want3, _ = orc.mine([o], [g.name], [""], fmin=1, pmin=1, emax=0.0)
         assert got == want3
     o.close()
+
+
+def test_index_residency_offload_and_reload(golden, pydsm_mod):
+    """an index gives its HBM back and comes back with one async copy; queries and miners refuse an offloaded
+    index; results after the reload are unchanged (a miner created before survives the cycle)."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    idx = [pydsm_mod.Index(golden.fmi("toy3", n)) for n in names]
+    pos = np.arange(0, idx[0].n, 7, dtype=np.uint64)
+    cs = np.full(len(pos), ord("C"), np.uint8)
+    before = idx[0].lf_batch(cs, pos)
+    full = idx[0].device_bytes()
+    with pydsm_mod.Miner(idx, fmin=2, emax=2.0) as m:
+        want = golden.server_out("toy3", "default", "GT")
+        assert m.mine("GT")[0] == want
+        for ix in idx:
+            ix.offload()
+            assert not ix.resident and ix.device_bytes() < full // 4
+            ix.offload()                                   # idempotent
+        with pytest.raises(pydsm_mod.DsmError):
+            idx[0].lf_batch(cs, pos)
+        with pytest.raises(pydsm_mod.DsmError):
+            m.mine("GT")
+        for ix in idx:
+            ix.reload()
+            assert ix.resident and ix.device_bytes() == full
+        assert (idx[0].lf_batch(cs, pos) == before).all()
+        assert m.mine("GT")[0] == want
+        idx[1].offload(); idx[1].reload()                 # second cycle reuses the pinned copy
+        assert m.mine("A")[0] == golden.server_out("toy3", "default", "A")
+    k = pydsm_mod.Index(golden.fmi("toy3", names[0]), keep_wt=True)
+    with pytest.raises(pydsm_mod.DsmError):
+        k.offload()
+    k.close()
+    for ix in idx:
+        ix.close()
