@@ -731,8 +731,15 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u16* __restrict__ 
                                   const u16* __restrict__ order16, const u8* __restrict__ cand, const u64* __restrict__ keyscan,
                                   const u32* __restrict__ idx32,
                                   u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= a.F || !cand[v]) return;
+    // a thread looks at eight consecutive flags with one load (few nodes are candidates: a thread per node is mostly idle)
+    const u32 v8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
+    if (v8 >= a.F) return;
+    u64 flags = 0;
+    if (v8 + 8 <= a.F) flags = *reinterpret_cast<const u64*>(cand + v8);
+    else for (u32 q = 0; v8 + q < a.F; ++q) flags |= (u64)cand[v8 + q] << (8 * q);
+    while (flags) {
+    const u32 v = v8 + (u32)((__ffsll((long long)flags) - 1) >> 3);
+    flags &= flags - 1;  // flags are 0 or 1 per byte
     const u32 k = keyscan ? (u32)(keyscan[v] & 0xFFFFFFFFu) : idx32[v];
     u32 o = keyscan ? (u32)(keyscan[v] >> 32) : k;
     cand_node[k] = v;
@@ -758,6 +765,7 @@ __global__ void cand_store_kernel(FilterArgs a, Xchg x, const u16* __restrict__ 
             if (f) { ids[o] = g; freqs[o] = f; ++o; }
         }
     }
+    }  // flags
 }
 
 // stream mode (one sample): frequency and left char of every node of the level are retained for the wire stream
@@ -2029,7 +2037,7 @@ class Engine {
             EARENA_GET(me.ids, u32, me.npairs);
             EARENA_GET(me.freqs, u64, me.npairs);
             me.ncand = nc;
-            hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag,
+            hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(((u64)F + 7) / 8), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag,
                                one ? (const u64*)nullptr : cand_keyscan, idx32, me.cand_node, me.cand_poff, me.ids, me.freqs);
         }
         stats.candidates += me.ncand;
