@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     }
 }
 
+constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
 // view of one exchange buffer: rank-major; inside a rank [nlocal][F] P (frequency of node v in the sample, 0 = absent)
 // then [nlocal][F] u8 (bits 0-3: surviving children of v in the sample, bits 4-6: left-char code of v)
 struct Xchg {
@@ -375,7 +376,7 @@ template <typename P>
 __device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
-    const u8* rb = x.base + (u64)r * x.bpr;
+    const u8* rb = x.base + (u64)r * x.bpr + XHDR;
     if (x.fb == 2) return (P)reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v];
     return reinterpret_cast<const P*>(rb)[(u64)l * x.F + v];
 }
@@ -383,7 +384,7 @@ template <typename P>
 __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
-    const u8* rb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
+    const u8* rb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
     return rb[(u64)l * x.F + v];
 }
 
@@ -403,7 +404,7 @@ __device__ __forceinline__ void slots_eval8(const Xchg& x, u64 u0, u32 nTs[ADV_S
     const bool two = u0 + 1 < x.F;
     const u32 world = x.d / x.nlocal;
     for (u32 r = 0; r < world; ++r) {
-        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
+        const u8* pb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
         for (u32 l = 0; l < x.nlocal; ++l) {
             const u8* q = pb + (u64)l * x.F + u0;
             u32 m = (u32)(q[0] & 15) | (two ? (u32)(q[1] & 15) << 4 : 0u);
@@ -463,8 +464,10 @@ struct PublishArgs {
     const u32* src[4];
     u32* dst[4];
     u32 words[4];
+    u32* clear;   // header of the message the next level's expand kernels will fill (4 words), may be null
 };
 __global__ void publish_kernel(PublishArgs a) {
+    if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         for (u32 q = threadIdx.x; q < a.words[k]; q += blockDim.x) a.dst[k][q] = a.src[k][q];
@@ -477,7 +480,7 @@ __device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) nT4[c] = 0;
     for (u32 r = 0; r < world; ++r) {
-        const u8* pb = x.base + (u64)r * x.bpr + (u64)x.nlocal * x.F * x.fb;
+        const u8* pb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
         for (u32 l = 0; l < x.nlocal; ++l) {
             const u32 m = pb[(u64)l * x.F + u];
 #pragma unroll
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
         for (u32 q = threadIdx.x; q < o.nlocal * ALLOC_SHARDS; q += blockDim.x) { o.h_alloc[q] = o.alloc[q * ALLOC_PITCH]; o.alloc[q * ALLOC_PITCH] = 0; }
         const u32 world = x.d / x.nlocal;
         for (u32 r = threadIdx.x; r < world; r += blockDim.x)
-            o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr + x.bpr - 16);
+            o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr);
     }
 }
 
@@ -1761,11 +1764,14 @@ class Engine {
         int xcur = 0;     // exchange buffer that will receive the current level's children
         u32 F = 1;
         u32 depth = 0;
-        while (true) {
+        // The expand launch of a level is queued as early as possible: for level L+1 right after the synchronisation of
+        // level L, ahead of that level's remaining small launches (order, candidate store), so the GPU does not wait for
+        // the host to get through them.
+        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16) -> int {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
             const u32 fb = w16 ? 2u : (u32)sizeof(P);
-            // per rank: [nlocal][F] frequencies, [nlocal][F] bytes, padding, then one u64: largest child frequency of this level
+            // per rank: 16-byte header (largest child frequency of this level), [nlocal][F] frequencies, [nlocal][F] bytes, padding
             const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
             u8* send = world > 1 ? xsend : xrecv[xcur];
@@ -1773,8 +1779,7 @@ class Engine {
             memset(&ea, 0, sizeof ea);
             ea.F = F; ea.cap = Rcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
             ea.ns_mask = ns_shards - 1; ea.region = region;
-            unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send + bpr - 16);
-            DSM_HIP(hipMemsetAsync(d_childmax, 0, 16, st));
+            unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send);  // header, cleared by the previous level's publish kernel
             if (depth < prefix.size()) {
                 const char* q = strchr(bases, prefix[depth]);
                 ea.allowed = 1u << (q - bases);
@@ -1788,8 +1793,8 @@ class Engine {
             DSM_HIP(hipEventRecord(ea0, st));
             for (int s = 0; s < nlocal && trie_mode; ++s) {  // children, frequency and left char come from the parsed stream
                 const dsm_trie* t = tries[s];
-                P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);
-                u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;
+                P* cf = reinterpret_cast<P*>(send + XHDR + (size_t)s * F * fb);
+                u8* cl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;
                 if (depth + 1 < t->level_off.size()) {
                     const u64 o = t->level_off[depth];
                     hipLaunchKernelGGL((trie_expand_kernel<P>), grid_for(F), dim3(256), 0, st, F, rp[cur][s], t->d_freq + o, t->d_pl + o, t->d_fc + o, cf, cl, tpos[s], ea.allowed);
@@ -1804,14 +1809,23 @@ class Engine {
                 ea.sb.one_sb = (m.n >> SB_SHIFT) == 0 ? 1u : 0u;
                 for (int c = 0; c < 4; ++c) ea.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
-                P* cf = reinterpret_cast<P*>(send + (size_t)s * F * fb);                  // this sample's frequency column
-                u8* cl = send + (size_t)nlocal * F * fb + (size_t)s * F;                  // children nibble | left char << 4
+                P* cf = reinterpret_cast<P*>(send + XHDR + (size_t)s * F * fb);           // this sample's frequency column
+                u8* cl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;           // children nibble | left char << 4
                 hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + (size_t)s * ALLOC_SHARDS * ALLOC_PITCH,
                                    tpos[s], cf, cl, ea, d_counters, (d == 1 && !trie_mode) ? blockcnt : (u32*)nullptr, d_childmax);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
             DSM_HIP(hipGetLastError());
+            return 0;
+        };
+        DSM_HIP(hipMemsetAsync(world > 1 ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
+        if (int rc = launch_expand(F, depth, cur, xcur, w16)) return rc;
+        while (true) {
+            const u64 slots = (u64)F * 4;
+            const u32 fb = w16 ? 2u : (u32)sizeof(P);
+            const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
+            const int nxt = cur ^ 1;
             // ---- exchange: one all-gather per level ----------------------------------------------
             if (world > 1) {
                 int rc = prm.allgather(prm.allgather_ctx, xsend, xrecv[xcur], (size_t)bpr, (void*)st);
@@ -1875,6 +1889,7 @@ class Engine {
                 if (filtered) {
                     pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
                 }
+                pa.clear = reinterpret_cast<u32*>(world > 1 ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, st, pa);
             }
             DSM_HIP(hipStreamSynchronize(st));
@@ -1893,6 +1908,7 @@ class Engine {
             if (Fn) {
                 child.slot = arena.get<u32>(Fn);  // same address as new_slot2
                 ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
+                if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16)) return rc;  // w16 already describes the next level
                 // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
                 if (!(emit || capture)) {}
                 else if (order_mode == 1)

@@ -145,7 +145,7 @@ typedef int (*dsm_tuple_sink)(void* ctx, const dsm_tuple_batch* batch);
 
 /* One exchange per frontier level (per frontier node and local sample: the node's frequency in 2 bytes -- 4 or 8 on the
  * few top levels where frequencies reach 65535 -- and one byte with the four "child survives fmin" bits and its left-char
- * code, plus 16 trailing bytes per rank): every rank contributes bytes_per_rank bytes at sendbuf and must end
+ * code, behind a 16-byte header per rank): every rank contributes bytes_per_rank bytes at sendbuf and must end
  * up with world_size * bytes_per_rank bytes at recvbuf, rank-major (ncclAllGather semantics).  Device
  * pointers; must be ordered after prior work on `stream` and before later work on it. */
 typedef int (*dsm_allgather_fn)(void* ctx, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
