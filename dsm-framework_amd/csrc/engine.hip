@@ -17,6 +17,7 @@
 // of a prefix from subtree aggregates over the retained levels (prefix sums, no sorting).
 #include <sched.h>
 
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -465,12 +466,17 @@ struct PublishArgs {
     u32* dst[4];
     u32 words[4];
     u32* clear;   // header of the message the next level's expand kernels will fill (4 words), may be null
+    u32* flag;    // pinned: receives `seq` after everything above is visible to the host (the host spins on it)
+    u32 seq;
 };
 __global__ void publish_kernel(PublishArgs a) {
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         for (u32 q = threadIdx.x; q < a.words[k]; q += blockDim.x) a.dst[k][q] = a.src[k][q];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // how many samples keep each child of parent u (0 = the slot is not a union node)
@@ -1424,6 +1430,7 @@ class Engine {
 
     // frontier buffers
     u32 Fcap = 0;
+    u32 pub_seq = 0;          // sequence number of the last publish kernel
     u32 Rcap = 0;             // handles of a record buffer (Fcap plus the slack of the windowed allocation)
     u32 ns_shards = 1, region = 0;
     u32* h_alloc = nullptr;   // pinned [nlocal][ALLOC_SHARDS]
@@ -1890,9 +1897,23 @@ class Engine {
                     pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
                 }
                 pa.clear = reinterpret_cast<u32*>(world > 1 ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
+                pa.flag = h_totals + 310; pa.seq = ++pub_seq;
                 hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, st, pa);
             }
-            DSM_HIP(hipStreamSynchronize(st));
+            {   // the publish kernel is the last work queued: its flag in pinned memory is this level's completion.  Spinning on
+                // it returns a few microseconds after the store; a stream synchronisation wakes the thread later.
+                volatile u32* fl = h_totals + 310;
+                u32 spins = 0;
+                while (*fl != pub_seq) {
+                    if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the flag?
+                        DSM_HIP(hipStreamSynchronize(st));
+                        if (*fl != pub_seq) return fail(DSM_E_HIP, "publish kernel did not report");
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
             const u32 Fn = h_totals[0];
             {
                 u64 mx = 0;
