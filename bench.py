@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--fmin", type=int, default=10)
     ap.add_argument("--emax", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    ap.add_argument("--force-exchange", action="store_true", help="rehearsal at N=1: drive the whole multi-rank exchange path (send buffer, "
+                    "one RCCL all-gather per level through torch.distributed, lanes, status words) with a world of one")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmin", type=int, default=-1, help="metaserver -P; default 1 for a single sample, else 2")
     ap.add_argument("--pmax", type=int, default=0, help="metaserver --pmax (BASELINE configs[3]: 8, configs[4]: 1)")
@@ -124,6 +126,12 @@ def main():
     local = local % max(1, ndev)  # rehearsals with more ranks than cards (DSM_BENCH_BACKEND=gloo) share a card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    forced = bool(args.force_exchange) and world == 1
+    if forced:
+        os.environ["DSM_FORCE_EXCHANGE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group(os.environ.get("DSM_BENCH_BACKEND", "nccl"), rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DSM_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
@@ -156,17 +164,17 @@ def main():
     # default communicator; pydsm.dist.TurnGate makes them enqueue their collectives in strict alternation, i.e. in the same
     # order on every rank (each lane issues the same number of collectives everywhere because every rank walks the same
     # union trie).  DSM_BENCH_LANES / --lanes override.
-    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 else "2"))
+    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 and not forced else "2"))
     nlanes = max(1, min(nlanes, len(prefixes)))
     lanes = []
     gate = None
-    if world > 1 and nlanes > 1:
+    if (world > 1 or forced) and nlanes > 1:
         from pydsm.dist import TurnGate
         gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
     for j in range(nlanes):
         lane = {"prefixes": prefixes[j::nlanes], "stream": torch.cuda.Stream(device=dev) if nlanes > 1 else torch.cuda.current_stream()}
         allgather = exchange = None
-        if world > 1:
+        if world > 1 or forced:
             from pydsm.dist import Exchange
             group = None  # the default communicator, shared by the lanes
             lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
@@ -179,7 +187,7 @@ def main():
             arena = int(min(want, free_b * 0.7 / (nlanes - j) / sharing))
         lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
                                     allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
-                                    emit_owner_only=world > 1, arena_bytes=arena, wide=1 if args.wide else 0,
+                                    emit_owner_only=world > 1 or forced, arena_bytes=arena, wide=1 if args.wide else 0,
                                     stream_mode=args.stream_mode)
         lanes.append(lane)
     if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
@@ -321,7 +329,7 @@ def main():
         print(json.dumps(out), flush=True)
     for x in ixs:
         x.close()
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1430,6 +1430,7 @@ class Engine {
 
     // frontier buffers
     u32 Fcap = 0;
+    bool multi = false;       // the level exchange goes through the host's all-gather (world > 1, or forced for rehearsals)
     u32 pub_seq = 0;          // sequence number of the last publish kernel
     u32 Rcap = 0;             // handles of a record buffer (Fcap plus the slack of the windowed allocation)
     u32 ns_shards = 1, region = 0;
@@ -1520,6 +1521,8 @@ class Engine {
         nlocal = n;
         world = p.world_size > 1 ? (int)p.world_size : 1;
         rank = world > 1 ? (int)p.rank : 0;
+        // rehearsal aid: a single rank that still drives the whole exchange path (send buffer, callback, status words)
+        multi = world > 1 || (p.allgather && getenv("DSM_FORCE_EXCHANGE"));
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
         if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 273 local samples per process");
@@ -1549,7 +1552,7 @@ class Engine {
         if (fc > fbound) fc = fbound < 1024 ? 1024 : fbound;
         Fcap = (u32)fc;
         bpr_cap = (((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull) + 16;
-        if (p.exchange_send && p.exchange_recv && world > 1) {
+        if (p.exchange_send && p.exchange_recv && multi) {
             if (p.exchange_bytes < 1024) return fail(DSM_E_INVAL, "exchange buffers too small");
             // caller-owned buffers bound the frontier as well; recv holds 2 * world * exchange_bytes, used as two halves
             u64 cap_slots = (p.exchange_bytes - 32) / ((u64)nlocal * (sizeof(P) + 1));
@@ -1561,11 +1564,11 @@ class Engine {
         } else {
             if (int rc = dalloc(xrecv[0], (size_t)world * bpr_cap)) return rc;
             if (int rc = dalloc(xrecv[1], (size_t)world * bpr_cap)) return rc;
-            if (world > 1) { if (int rc = dalloc(xsend, (size_t)bpr_cap)) return rc; }
+            if (multi) { if (int rc = dalloc(xsend, (size_t)bpr_cap)) return rc; }
         }
         // every rank must take the same capacity decisions (a prefix that overflows is split on all ranks or on none):
         // agree on the smallest frontier capacity through the host's all-gather
-        if (world > 1) {
+        if (multi) {
             u64 mine = Fcap, agreed = 0;
             if (int rc = agree_min(mine, &agreed)) return rc;
             Fcap = (u32)agreed;
@@ -1632,7 +1635,7 @@ class Engine {
         u64 arena_b = budget > used ? budget - used : 0;
         const u64 floor_b = p.arena_bytes ? (1u << 20) : (64u << 20);  // an explicit budget is honoured down to 1 MiB
         if (arena_b < floor_b) arena_b = floor_b;
-        if (world > 1) {
+        if (multi) {
             u64 agreed = 0;
             if (int rc = agree_min(arena_b, &agreed)) return rc;
             arena_b = agreed;
@@ -1640,7 +1643,7 @@ class Engine {
         if (int rc = dalloc(arena.base, arena_b)) return rc;
         arena.cap = arena_b;
         ea = &arena;
-        if (world > 1 && !stream_mode) {  // 60 % structure (identical on every rank), 40 % emission
+        if (multi && !stream_mode) {  // 60 % structure (identical on every rank), 40 % emission
             arena.cap = (size_t)(arena_b * 0.6) & ~(size_t)255;
             earena.base = arena.base + arena.cap;
             earena.cap = arena_b - arena.cap;
@@ -1781,7 +1784,7 @@ class Engine {
             // per rank: 16-byte header (largest child frequency of this level), [nlocal][F] frequencies, [nlocal][F] bytes, padding
             const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
-            u8* send = world > 1 ? xsend : xrecv[xcur];
+            u8* send = multi ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
             ea.F = F; ea.cap = Rcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
@@ -1826,7 +1829,7 @@ class Engine {
             DSM_HIP(hipGetLastError());
             return 0;
         };
-        DSM_HIP(hipMemsetAsync(world > 1 ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
+        DSM_HIP(hipMemsetAsync(multi ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
         if (int rc = launch_expand(F, depth, cur, xcur, w16)) return rc;
         while (true) {
             const u64 slots = (u64)F * 4;
@@ -1834,7 +1837,7 @@ class Engine {
             const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
             // ---- exchange: one all-gather per level ----------------------------------------------
-            if (world > 1) {
+            if (multi) {
                 int rc = prm.allgather(prm.allgather_ctx, xsend, xrecv[xcur], (size_t)bpr, (void*)st);
                 if (rc) return fail(DSM_E_SINK, "allgather callback failed");
             }
@@ -1856,7 +1859,7 @@ class Engine {
             bool filtered = false;
             if (emit_here) {
                 int erc = emit_alloc(me, F);
-                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }  // agreed on at the end of the prefix
+                if (erc == DSM_E_CAPACITY && multi) { emit_failed = true; emitting = false; }  // agreed on at the end of the prefix
                 else if (erc) return erc;
                 else filtered = true;
             }
@@ -1896,7 +1899,7 @@ class Engine {
                 if (filtered) {
                     pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
                 }
-                pa.clear = reinterpret_cast<u32*>(world > 1 ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
+                pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 pa.flag = h_totals + 310; pa.seq = ++pub_seq;
                 hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, st, pa);
             }
@@ -1972,7 +1975,7 @@ class Engine {
             }
             if (filtered) {  // the candidates of this level: totals arrived with the synchronisation above
                 int erc = emit_store(me, F, depth, x, cur, order_mode);
-                if (erc == DSM_E_CAPACITY && world > 1) { emit_failed = true; emitting = false; }
+                if (erc == DSM_E_CAPACITY && multi) { emit_failed = true; emitting = false; }
                 else if (erc) return erc;
             }
             DSM_HIP(hipGetLastError());
@@ -1995,10 +1998,10 @@ class Engine {
         } else {
             if (emitting) {
                 int rc = finish_mine(L, nlev, tsink, ctx, &ready);
-                if (rc == DSM_E_CAPACITY && world > 1) { emit_failed = true; ready = false; }
+                if (rc == DSM_E_CAPACITY && multi) { emit_failed = true; ready = false; }
                 else if (rc) return rc;
             }
-            if (world > 1) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
+            if (multi) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
                 u64 ok = emit_failed ? 0 : 1, all_ok = 0;
                 if (int rc = agree_min(ok, &all_ok)) return rc;
                 if (!all_ok) return fail(DSM_E_CAPACITY, "device arena exhausted on a rank: use a longer prefix or a larger arena_bytes");

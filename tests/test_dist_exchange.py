@@ -170,3 +170,80 @@ def test_turn_gate_interleaves_lanes_deterministically():
             t.join(10)
         assert log == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3), (0, 4), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8)]
         gate.reset()
+
+
+def _nccl_worker(port, q):
+    """One RCCL rank (two ranks cannot share a card under RCCL): the exchange exactly as bench.py drives it at N > 1 --
+    two lane threads, each with its own HIP stream, collectives of the ONE default communicator ordered by a TurnGate."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+    from pydsm.dist import Exchange, TurnGate
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        gate = TurnGate(2)
+        lanes = []
+        for j in range(2):
+            st = torch.cuda.Stream(device=dev)
+            lanes.append((st, Exchange(1 << 16, 1, dev, stream=st, gate=gate, lane=j)))
+        ok = [True, True]
+
+        def run(j):
+            st, ex = lanes[j]
+            gate.begin(j)
+            try:
+                with torch.cuda.stream(st):
+                    for level, nbytes in enumerate([16, 4096, 48, 65536, 32] * 8):
+                        ex.send[:nbytes] = (level * 7 + j) % 251
+                        half = (level & 1) * ex.nbytes * ex.world
+                        ex.allgather(ex.send.data_ptr(), ex.recv.data_ptr() + half, nbytes, st.cuda_stream)
+                        st.synchronize()
+                        got = ex.recv[half: half + nbytes]
+                        ok[j] = ok[j] and bool((got == (level * 7 + j) % 251).all())
+            finally:
+                gate.retire(j)
+        ths = [threading.Thread(target=run, args=(j,)) for j in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        calls = [ex.calls for _, ex in lanes]
+        dist.destroy_process_group()
+        q.put(("ok", ok, calls))
+    except Exception as e:  # noqa: BLE001
+        q.put(("err", repr(e), None))
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_from_two_lane_threads_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(timeout=60)
+    assert res[0] == "ok", res
+    assert res[1] == [True, True] and res[2] == [40, 40]
+
+
+@pytest.mark.gpu
+def test_bench_forced_exchange_rehearsal_on_rccl(tmp_path):
+    """bench.py --force-exchange: one rank drives the complete N > 1 path (send buffer, one RCCL all-gather per level through
+    torch.distributed, two lane threads under the turn gate, capacity agreement, per-prefix status words, owner-only emission)
+    and must report exactly the nodes and tuples of the plain single-rank run."""
+    import json
+    import subprocess
+    env = dict(os.environ, DSM_BENCH_DIR=str(tmp_path))
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--reads", "200000", "--genome", "1000000"]
+    outs = []
+    for extra in ([], ["--force-exchange"]):
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = outs
+    assert b["config"]["parallelism"].endswith("2 prefix lane(s) per GPU")
+    for k in ("rank0_nodes_per_step", "tuples_per_step", "union_nodes_per_step", "candidates_per_step", "rank_ops_per_node"):
+        assert a["detail"][k] == b["detail"][k], k
