@@ -315,7 +315,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),
-                         "alg_bytes_per_launch": tot["rank_ops"] * ALG_BYTES_PER_RANK / max(1, tot["launches"])},
+                         "alg_bytes_per_launch": tot["rank_ops"] * ALG_BYTES_PER_RANK / max(1, tot["launches"]),
+                         # with more than one lane the expand launches of the lanes share the device: their durations
+                         # (and so `achieved`) describe two kernels running side by side, not one kernel alone
+                         "concurrent_lanes": nlanes},
             "detail": {"rank0_nodes_per_step": tot["reported"] / max(1, args.steps), "rank_ops_per_node": tot["rank_ops"] / max(1, tot["reported"]),
                        "lf_per_node": tot["lf_steps"] / max(1, tot["reported"]), "tuples_per_step": tot["tuples"] / max(1, args.steps),
                        "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
