@@ -313,7 +313,10 @@ def main():
                                                                               ", wire-stream mode" if args.stream_mode else "", len(prefixes)),
                        "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
+                         "traffic": traffic,
+                         # the same kernel priced by its measured HBM traffic (profiles/traffic.json) instead of the reference's rank-ops
+                         "traffic_gbs": (traffic / (tot["expand_ms"] / max(1, tot["launches"]) * 1e-3) / 1e9) if traffic and tot["expand_ms"] > 0 else None,
+                         "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),
                          "alg_bytes_per_launch": tot["rank_ops"] * ALG_BYTES_PER_RANK / max(1, tot["launches"]),
                          # with more than one lane the expand launches of the lanes share the device: their durations
