@@ -358,6 +358,16 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
 }
 
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
+// Several engines of one process (prefix lanes on their own streams) share the device.  Their expand launches are chained:
+// each waits for the previously issued expand of the process on that device, so two LF-step kernels never run side by
+// side (their per-launch durations stay meaningful) while everything else of one lane overlaps the other lane's expand.
+struct ExpandChain {
+    std::mutex mu;
+    hipEvent_t last[16] = {nullptr};   // per device: completion of the most recently issued expand launch
+    const void* owner[16] = {nullptr};
+};
+static ExpandChain g_expand_chain;
+
 // view of one exchange buffer: rank-major; inside a rank [nlocal][F] P (frequency of node v in the sample, 0 = absent)
 // then [nlocal][F] u8 (bits 0-3: surviving children of v in the sample, bits 4-6: left-char code of v)
 struct Xchg {
@@ -1475,6 +1485,11 @@ class Engine {
         if (h_childmax) (void)hipHostFree(h_childmax);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        {   // nobody may wait on an event of this engine any more
+            std::lock_guard<std::mutex> lk(g_expand_chain.mu);
+            for (int dv = 0; dv < 16; ++dv)
+                if (g_expand_chain.owner[dv] == this) { g_expand_chain.owner[dv] = nullptr; g_expand_chain.last[dv] = nullptr; }
+        }
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (fill_done) (void)hipEventDestroy(fill_done);
@@ -1800,6 +1815,9 @@ class Engine {
             }
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
+            std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
+            if (device < 16 && g_expand_chain.last[device] && g_expand_chain.owner[device] != this)
+                DSM_HIP(hipStreamWaitEvent(st, g_expand_chain.last[device], 0));
             DSM_HIP(hipEventRecord(ea0, st));
             for (int s = 0; s < nlocal && trie_mode; ++s) {  // children, frequency and left char come from the parsed stream
                 const dsm_trie* t = tries[s];
@@ -1826,6 +1844,8 @@ class Engine {
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
+            if (device < 16) { g_expand_chain.last[device] = ea1; g_expand_chain.owner[device] = this; }
+            chain_lock.unlock();
             DSM_HIP(hipGetLastError());
             return 0;
         };
