@@ -61,12 +61,13 @@ def build_index(args, rank, dev):
     import torch
     from pydsm import builder
     os.makedirs(args.workdir, exist_ok=True)
-    tag = "s%d_r%d_l%d_g%d_e%g" % (42 + rank, args.reads, args.rlen, args.genome, args.sub_rate)
+    private = 0.05 if args.gpus * args.nlocal > 1 else 0.0  # SURVEY 8d cfg 3: sample-specific 5 % when there are several samples
+    tag = "s%d_r%d_l%d_g%d_e%g%s" % (42 + rank, args.reads, args.rlen, args.genome, args.sub_rate, "_p%g" % private if private else "")
     path = os.path.join(args.workdir, "sample-%d.%s.fmi" % (rank, tag))
     t0 = time.time()
     if not os.path.exists(path):
         codes = builder.synth_reads(42 + rank, args.reads, args.rlen, args.genome, args.sub_rate, device=dev,
-                                    private_frac=0.05 if args.gpus * args.nlocal > 1 else 0.0)
+                                    private_frac=private)
         builder.build_from_codes(codes, path + ".tmp")
         del codes
         torch.cuda.empty_cache()
