@@ -37,6 +37,7 @@ struct DmArgs {
     double* mlog;
     double* msqrt;
     double* mlgamma;
+    const double* nfactor;  // -N: 1 / dataset size per sample (null: raw frequencies)
 };
 
 __device__ __forceinline__ void dm_pair_of(u32 p, u32 s, u32& j, u32& k) {  // p-th pair (j < k) in row-major order
@@ -102,13 +103,18 @@ __global__ __launch_bounds__(DM_THREADS) void distmat_kernel(DmArgs a) {
                     else atomicAdd(&a.count[cell], 1u);
                 }
                 if (fj || fk) {  // add() :174-196
-                    const double lj = log((double)fj + 1.0), lk = log((double)fk + 1.0);
-                    const double sj = sqrt((double)fj), sk = sqrt((double)fk);
-                    const double dl = lj - lk, ds = sj - sk;
-                    const double lg = lgamma((double)fj + (double)fk + 1.0) - lgamma((double)fj + 1.0) - lgamma((double)fk + 1.0) -
-                                      ((double)fj + (double)fk + 1.0);
-                    if (a.use_lds) { atomicAdd(&l_log[cell], dl * dl); atomicAdd(&l_sqrt[cell], ds * ds); atomicAdd(&l_lgam[cell], lg); }
-                    else { atomicAdd(&a.mlog[cell], dl * dl); atomicAdd(&a.msqrt[cell], ds * ds); atomicAdd(&a.mlgamma[cell], lg); }
+                    double dl, ds, lg = 0;
+                    if (a.nfactor) {  // add_normalized(), smtxt2entropy.c:199-228: the lgamma term is disabled there
+                        const double xj = (double)fj * a.nfactor[j], xk = (double)fk * a.nfactor[k];
+                        dl = log(xj + 1.0) - log(xk + 1.0);
+                        ds = sqrt(xj) - sqrt(xk);
+                    } else {
+                        dl = log((double)fj + 1.0) - log((double)fk + 1.0);
+                        ds = sqrt((double)fj) - sqrt((double)fk);
+                        lg = lgamma((double)fj + (double)fk + 1.0) - lgamma((double)fj + 1.0) - lgamma((double)fk + 1.0) - ((double)fj + (double)fk + 1.0);
+                    }
+                    if (a.use_lds) { atomicAdd(&l_log[cell], dl * dl); atomicAdd(&l_sqrt[cell], ds * ds); if (!a.nfactor) atomicAdd(&l_lgam[cell], lg); }
+                    else { atomicAdd(&a.mlog[cell], dl * dl); atomicAdd(&a.msqrt[cell], ds * ds); if (!a.nfactor) atomicAdd(&a.mlgamma[cell], lg); }
                 }
             }
         }
@@ -133,6 +139,10 @@ struct dsm_distmat {
     u32 s = 0, nm = 0, minfreq = 0;
     std::vector<double> maxent;       // sorted descending (smtxt2entropy.c:71-78, :542)
     std::vector<u32> noutput;         // per bucket, not yet cumulative
+    u32 runs = 0;                     // ids accepted in the input (== s without a mapping)
+    std::vector<int> run_to_sample;   // -S
+    std::vector<double> nfactor;      // -N: 1 / size
+    double* d_nfactor = nullptr;
     u32* d_count = nullptr;
     double *d_log = nullptr, *d_sqrt = nullptr, *d_lgamma = nullptr;
     // upload staging (grown on demand)
@@ -162,6 +172,11 @@ int dsm_distmat_steps(double step, double* out, int cap) {  // smtxt2entropy.c:2
 }
 
 int dsm_distmat_create(int device, uint32_t samples, const double* maxent, uint32_t nmaxent, uint32_t minfreq, dsm_distmat** out) {
+    return dsm_distmat_create_ex(device, samples, maxent, nmaxent, minfreq, nullptr, 0, nullptr, out);
+}
+
+int dsm_distmat_create_ex(int device, uint32_t samples, const double* maxent, uint32_t nmaxent, uint32_t minfreq,
+                          const int32_t* run_to_sample, uint32_t runs, const double* sizes, dsm_distmat** out) {
     if (!out || !maxent || nmaxent < 1 || nmaxent > 127) return fail(DSM_E_INVAL, "dsm_distmat_create: bad argument");
     if (samples < 2) return fail(DSM_E_INVAL, "the number of samples must be at least 2 (smtxt2entropy.c:560)");
     if (samples > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
@@ -176,11 +191,29 @@ int dsm_distmat_create(int device, uint32_t samples, const double* maxent, uint3
     m->maxent.assign(maxent, maxent + nmaxent);
     std::sort(m->maxent.begin(), m->maxent.end(), [](double x, double y) { return x > y; });
     m->noutput.assign(nmaxent, 0);
+    m->runs = samples;
+    if (run_to_sample) {
+        if (runs < samples) { delete m; return fail(DSM_E_INVAL, "unable to use the run-to-sample mapping: fewer runs than samples (smtxt2entropy.c:571-572)"); }
+        for (u32 i = 0; i < runs; ++i)
+            if (run_to_sample[i] < 0 || (u32)run_to_sample[i] >= samples) { delete m; return fail(DSM_E_INVAL, "run-to-sample mapping: sample id out of range"); }
+        m->runs = runs;
+        m->run_to_sample.assign(run_to_sample, run_to_sample + runs);
+    }
+    if (sizes) {
+        for (u32 i = 0; i < samples; ++i)
+            if (!(sizes[i] != 0)) { delete m; return fail(DSM_E_INVAL, "dataset sizes must be non-zero (smtxt2entropy.c:593)"); }
+        m->nfactor.resize(samples);
+        for (u32 i = 0; i < samples; ++i) m->nfactor[i] = (double)1 / sizes[i];
+    }
     const size_t cells = (size_t)nmaxent * samples * samples;
     if (hipMalloc(&m->d_count, cells * 4) != hipSuccess || hipMalloc(&m->d_log, cells * 8) != hipSuccess ||
         hipMalloc(&m->d_sqrt, cells * 8) != hipSuccess || hipMalloc(&m->d_lgamma, cells * 8) != hipSuccess) {
         dsm_distmat_destroy(m);
         return fail(DSM_E_NOMEM, "hipMalloc failed");
+    }
+    if (!m->nfactor.empty()) {
+        if (hipMalloc(&m->d_nfactor, samples * 8) != hipSuccess) { dsm_distmat_destroy(m); return fail(DSM_E_NOMEM, "hipMalloc failed"); }
+        (void)hipMemcpy(m->d_nfactor, m->nfactor.data(), samples * 8, hipMemcpyHostToDevice);
     }
     (void)hipMemset(m->d_count, 0, cells * 4); (void)hipMemset(m->d_log, 0, cells * 8);
     (void)hipMemset(m->d_sqrt, 0, cells * 8); (void)hipMemset(m->d_lgamma, 0, cells * 8);
@@ -191,7 +224,7 @@ int dsm_distmat_create(int device, uint32_t samples, const double* maxent, uint3
 void dsm_distmat_destroy(dsm_distmat* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    for (void* p : {(void*)m->d_count, (void*)m->d_log, (void*)m->d_sqrt, (void*)m->d_lgamma, m->d_pair_off, m->d_ids, m->d_freqs, m->d_bucket})
+    for (void* p : {(void*)m->d_count, (void*)m->d_log, (void*)m->d_sqrt, (void*)m->d_lgamma, m->d_pair_off, m->d_ids, m->d_freqs, m->d_bucket, (void*)m->d_nfactor})
         if (p) (void)hipFree(p);
     delete m;
 }
@@ -224,26 +257,38 @@ static int dm_accumulate(dsm_distmat* m, size_t nt, const u32* pair_off, const u
             P.off.push_back((u32)P.ids.size());
             seen.clear();
             for (u32 q = pair_off[t]; q < pair_off[t + 1]; ++q) {
-                const u32 run = ids[q];
+                u32 run = ids[q];
                 const unsigned frq = (unsigned)freqs[q];  // the tool reads frequencies with atoi into unsigned
-                if (run >= s) { P.err = 1; return; }
+                if (run >= m->runs) { P.err = 1; return; }
                 if (frq < m->minfreq) continue;
+                if (!m->run_to_sample.empty()) run = (u32)m->run_to_sample[run];  // several runs of one sample: the last one wins
                 bool dup = false;
                 for (u32 x : seen) dup |= x == run;
                 if (!dup) seen.push_back(run);
                 fq[run] = frq;
             }
             std::sort(seen.begin(), seen.end());
-            // entropy(), smtxt2entropy.c:128-145: unsigned 32-bit sumN, term-by-term log(x)/log(2)
-            unsigned sumN = s;
-            double sumNlogN = 0;
-            for (u32 x : seen) {
-                const unsigned frq = fq[x];
-                sumN += frq;
-                sumNlogN += (double)(frq + 1) * log(frq + 1) / LOG2;
+            double entr;
+            if (!m->nfactor.empty()) {  // normalized_entropy(), smtxt2entropy.c:147-165
+                double sumN = (double)(int)s, sumNlogN = 0;
+                for (u32 x : seen) {
+                    const double frq = (double)fq[x] * m->nfactor[x];
+                    sumN += frq;
+                    sumNlogN += (frq + 1) * log(frq + 1) / LOG2;
+                }
+                const double entropy = (log(sumN) / LOG2 - sumNlogN / sumN);
+                entr = LOG2 * entropy / LOGS;
+            } else {  // entropy(), smtxt2entropy.c:128-145: unsigned 32-bit sumN, term-by-term log(x)/log(2)
+                unsigned sumN = s;
+                double sumNlogN = 0;
+                for (u32 x : seen) {
+                    const unsigned frq = fq[x];
+                    sumN += frq;
+                    sumNlogN += (double)(frq + 1) * log(frq + 1) / LOG2;
+                }
+                const double entropy = (log(sumN) / LOG2 - sumNlogN / (double)sumN);
+                entr = LOG2 * entropy / LOGS;
             }
-            const double entropy = (log(sumN) / LOG2 - sumNlogN / (double)sumN);
-            const double entr = LOG2 * entropy / LOGS;
             int b = -1;
             for (int i = (int)nm; i > 0;) {
                 --i;
@@ -266,7 +311,7 @@ static int dm_accumulate(dsm_distmat* m, size_t nt, const u32* pair_off, const u
     std::vector<u32> o_off(nt + 1), o_ids, o_fr;
     {
         size_t tot = 0;
-        for (auto& P : pc) { if (P.err) return fail(DSM_E_INVAL, "dsm_distmat: sample id out of range (smtxt2entropy.c:96-101)"); tot += P.ids.size(); }
+        for (auto& P : pc) { if (P.err) return fail(DSM_E_INVAL, "dsm_distmat: run id out of range (smtxt2entropy.c:96-101)"); tot += P.ids.size(); }
         o_ids.reserve(tot); o_fr.reserve(tot);
         size_t t = 0;
         for (unsigned w = 0; w < nth; ++w) {
@@ -313,7 +358,7 @@ static int dm_accumulate(dsm_distmat* m, size_t nt, const u32* pair_off, const u
     a.use_lds = cells <= DM_LDS_CELLS ? 1u : 0u;
     a.pair_off = (const u32*)m->d_pair_off; a.ids = (const u32*)m->d_ids; a.freqs = (const u32*)m->d_freqs;
     a.bucket = (const signed char*)m->d_bucket;
-    a.count = m->d_count; a.mlog = m->d_log; a.msqrt = m->d_sqrt; a.mlgamma = m->d_lgamma;
+    a.count = m->d_count; a.mlog = m->d_log; a.msqrt = m->d_sqrt; a.mlgamma = m->d_lgamma; a.nfactor = m->d_nfactor;
     const u32 groups = DM_THREADS / G;
     size_t shm = (size_t)groups * s * 8 + 8 + (a.use_lds ? (size_t)cells * 28 : 0);
     u64 blocks = (nt + groups - 1) / groups;

@@ -1,8 +1,8 @@
 // smtxt2entropy_hip -- drop-in for wrapper-distance-matrix/smtxt2entropy.c (default mode): reads metaserver tuple
 // lines from stdin, accumulates the distance matrices on the GPU through libdsmhip's C ABI and writes the tool's four
 // files count.<suffix>, log.<suffix>, sqrt.<suffix>, lgamma.<suffix>.  Options as the reference (smtxt2entropy.c:482-556):
-//   -s,--samples N   -m,--maxent a,b,...  |  -e,--entstep x   -F,--file suffix   [-M,--minfreq n] [-v]
-// -S,--samplefile and -N,--normalize are not supported (exit 1).
+//   -s,--samples N | -S,--samplefile f   -m,--maxent a,b,...  |  -e,--entstep x   -F,--file suffix
+//   [-M,--minfreq n] [-N,--normalize sizes] [-v]
 #include <getopt.h>
 
 #include <cstdio>
@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     int smpls = -1, verbose = 0;
     unsigned minfreq = 0;
     std::vector<double> maxent;
-    std::string suffix;
+    std::string suffix, smplsfile, normfile;
     static struct option lo[] = {{"samples", required_argument, 0, 's'}, {"samplefile", required_argument, 0, 'S'},
                                  {"maxent", required_argument, 0, 'm'},  {"entstep", required_argument, 0, 'e'},
                                  {"file", required_argument, 0, 'F'},    {"normalize", required_argument, 0, 'N'},
@@ -53,9 +53,31 @@ int main(int argc, char** argv) {
         case 'F': suffix = optarg; break;
         case 'M': minfreq = (unsigned)atoi(optarg); break;
         case 'v': verbose = 1; break;
-        case 'S': case 'N': die("-S,--samplefile and -N,--normalize are not supported by smtxt2entropy_hip", argv[0]); break;
+        case 'S': smplsfile = optarg; break;
+        case 'N': normfile = optarg; break;
         default: fprintf(stderr, "usage: %s -s smpls (-m a,b,.. | -e step) -F suffix [-M minfreq] [-v] < tuples\n", argv[0]); return 1;
         }
+    }
+    if ((smpls == -1) == smplsfile.empty()) die("give either -s,--samples or -S,--samplefile, but not both.", argv[0]);
+    std::vector<int32_t> mapping;
+    if (!smplsfile.empty()) {  // parse_samples_file, smtxt2entropy.c:385-423: one sample id per line, line number = run id
+        FILE* f = fopen(smplsfile.c_str(), "rt");
+        if (!f) { fprintf(stderr, "error: sample file -S,--samplefile %s does not exist. Aborting!\n", smplsfile.c_str()); return 1; }
+        int v;
+        smpls = 0;
+        while (fscanf(f, "%d\n", &v) == 1) { mapping.push_back(v); if (v + 1 > smpls) smpls = v + 1; }
+        fclose(f);
+        if (smpls < 2 || (int)mapping.size() < smpls) die("unable to parse the samples file in the argument -S,--samplefile.", argv[0]);
+    }
+    std::vector<double> sizes;
+    if (!normfile.empty()) {   // parse_size_file, smtxt2entropy.c:425-455: "name<TAB>size" per sample
+        FILE* f = fopen(normfile.c_str(), "rt");
+        if (!f) { fprintf(stderr, "error: size file for -N,--normalize %s does not exist. Aborting!\n", normfile.c_str()); return 1; }
+        char name[128];
+        double x;
+        while ((int)sizes.size() < smpls && fscanf(f, "%100s\t%lf\n", name, &x) == 2) sizes.push_back(x);
+        fclose(f);
+        if ((int)sizes.size() != smpls) { fprintf(stderr, "error: unable to parse the file -N,--normalize %s.\n", normfile.c_str()); return 1; }
     }
     if (smpls < 2) die("the argument -s,--samples must be at least 2.", argv[0]);
     if (maxent.empty()) die("the argument -m,--maxent is mandatory.", argv[0]);
@@ -65,7 +87,8 @@ int main(int argc, char** argv) {
         if (FILE* f = fopen(fn.c_str(), "r")) { fclose(f); fprintf(stderr, "error: output file %s already exists. Aborting!\n", fn.c_str()); return 1; }
     }
     dsm_distmat* dm = nullptr;
-    if (dsm_distmat_create(0, (uint32_t)smpls, maxent.data(), (uint32_t)maxent.size(), minfreq, &dm)) {
+    if (dsm_distmat_create_ex(0, (uint32_t)smpls, maxent.data(), (uint32_t)maxent.size(), minfreq, mapping.empty() ? nullptr : mapping.data(),
+                              (uint32_t)mapping.size(), sizes.empty() ? nullptr : sizes.data(), &dm)) {
         fprintf(stderr, "error: %s\n", dsm_last_error());
         return 1;
     }

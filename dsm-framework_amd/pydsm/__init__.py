@@ -112,6 +112,8 @@ def lib():
         L.dsm_index_reload.argtypes = [C.c_void_p, C.c_void_p]
         L.dsm_index_resident.argtypes = [C.c_void_p]
         L.dsm_distmat_create.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.dsm_distmat_create_ex.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                            C.POINTER(C.c_void_p)]
         L.dsm_distmat_destroy.argtypes = [C.c_void_p]
         L.dsm_distmat_steps.argtypes = [C.c_double, C.c_void_p, C.c_int]
         L.dsm_distmat_add.argtypes = [C.c_void_p, C.POINTER(TupleBatch)]
@@ -377,7 +379,7 @@ class DistMat:
     """Distance matrices of a tuple stream (wrapper-distance-matrix/smtxt2entropy.c), accumulated on the GPU.
     add(batch) takes the batches a tuple sink receives (use as on_batch=dm.add), add_text() takes metaserver output lines."""
 
-    def __init__(self, samples, maxent=None, entstep=None, minfreq=0, device=0):
+    def __init__(self, samples, maxent=None, entstep=None, minfreq=0, device=0, run_to_sample=None, sizes=None):
         if (maxent is None) == (entstep is None):
             raise ValueError("give either maxent (list) or entstep")
         if entstep is not None:
@@ -389,7 +391,10 @@ class DistMat:
         self.samples, self.nm = int(samples), len(maxent)
         me = (C.c_double * self.nm)(*maxent)
         self.h = C.c_void_p()
-        _check(lib().dsm_distmat_create(device, self.samples, me, self.nm, minfreq, C.byref(self.h)))
+        mp = (C.c_int32 * len(run_to_sample))(*run_to_sample) if run_to_sample else None   # the tool's -S file
+        sz = (C.c_double * len(sizes))(*sizes) if sizes else None                         # the tool's -N file
+        _check(lib().dsm_distmat_create_ex(device, self.samples, me, self.nm, minfreq, mp, len(run_to_sample) if run_to_sample else 0, sz,
+                                           C.byref(self.h)))
 
     def add(self, batch):
         _check(lib().dsm_distmat_add(self.h, C.byref(batch)))

@@ -213,7 +213,7 @@ void dsm_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
  * Distance matrices of the tuple stream: the accumulation of wrapper-distance-matrix/smtxt2entropy.c
- * (default mode: no -S sample file, no -N normalisation) on the GPU.
+ * on the GPU.
  *   per tuple: normalised entropy (smtxt2entropy.c:128-145, evaluated on the host with the reference's expression
  *   and libm so that the bucket choice of :690-703 is exact), then for the chosen <max_entropy> bucket the pair
  *   counts and the three squared-distance sums of add() (:167-197) -- accumulated on the device.
@@ -222,6 +222,11 @@ void dsm_free(void* p);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dsm_distmat dsm_distmat;
 int dsm_distmat_create(int device, uint32_t samples, const double* maxent, uint32_t nmaxent, uint32_t minfreq, dsm_distmat** out);
+/* The tool's -S,--samplefile (run_to_sample[runs]: sample of every run id that may appear in the input; the matrices then
+ * have max + 1 = `samples` rows; smtxt2entropy.c:101-104,385-423) and -N,--normalize (sizes[samples]: dataset sizes;
+ * normalized_entropy :147-165, add_normalized :199-228 -- its lgamma matrix stays zero).  Either may be NULL. */
+int dsm_distmat_create_ex(int device, uint32_t samples, const double* maxent, uint32_t nmaxent, uint32_t minfreq,
+                          const int32_t* run_to_sample, uint32_t runs, const double* sizes, dsm_distmat** out);
 void dsm_distmat_destroy(dsm_distmat* m);
 /* -e,--entstep list of the tool (smtxt2entropy.c:258-285); returns the number of values written (<= cap) or < 0 */
 int dsm_distmat_steps(double step, double* out, int cap);

@@ -4,7 +4,8 @@
  * its text output byte for byte with tests/golden/<set>/distmat.* produced by the unmodified reference tool
  * (oracle/_ref/smtxt2entropy, tests/golden/make_golden_distmat.py).
  *
- * Restated: the default mode (no -S sample file, no -N normalisation).
+ * Restated: the default mode, the -S run-to-sample mapping (:101-104, 385-423) and the -N normalisation
+ * (normalized_entropy :147-165, add_normalized :199-228, factors and tables :585-611; its lgamma matrix stays 0).
  *   line parsing            smtxt2entropy.c:84-125, 656-680   (first token = path, second = entropy text when it
  *                                                             contains '.', then id:freq pairs; -M drops pairs)
  *   normalised entropy      smtxt2entropy.c:128-145           (unsigned 32-bit sumN, log(x)/log(2) term by term)
@@ -57,20 +58,55 @@ typedef struct {
     cell* m;         /* [nm][smpls][smpls] */
     unsigned minfreq;
     unsigned long rows;
+    int runs;        /* ids accepted in the input; == smpls without -S */
+    int* runtosmpl;  /* NULL without -S */
+    double* nfactor; /* NULL without -N: 1 / dataset size per sample */
+    double** prenormlog;
+    double** prenormsqrt;
 } dm;
 
 void* orc_distmat_new(int smpls, const double* maxent, int nmaxent, unsigned minfreq) {
     tables();
     if (smpls < 2 || smpls > MAXS || nmaxent < 1) return NULL;
     dm* d = (dm*)calloc(1, sizeof(dm));
-    d->smpls = smpls; d->nm = nmaxent; d->minfreq = minfreq;
+    d->smpls = smpls; d->nm = nmaxent; d->minfreq = minfreq; d->runs = smpls;
     d->par = (param*)calloc((size_t)nmaxent, sizeof(param));
     for (int i = 0; i < nmaxent; ++i) { d->par[i].maxent = maxent[i]; d->par[i].noutput = 0; }
     qsort(d->par, (size_t)nmaxent, sizeof(param), paramcmp);
     d->m = (cell*)calloc((size_t)nmaxent * smpls * smpls, sizeof(cell));
     return d;
 }
-void orc_distmat_free(void* h) { dm* d = (dm*)h; if (d) { free(d->par); free(d->m); free(d); } }
+void orc_distmat_free(void* h) {
+    dm* d = (dm*)h;
+    if (!d) return;
+    if (d->prenormlog) for (int i = 0; i < d->smpls; ++i) { free(d->prenormlog[i]); free(d->prenormsqrt[i]); }
+    free(d->prenormlog); free(d->prenormsqrt); free(d->nfactor); free(d->runtosmpl);
+    free(d->par); free(d->m); free(d);
+}
+/* -S: runtosmpl[runs] (sample of every run id); -N: sizes[smpls] (dataset sizes).  Either may be NULL. */
+int orc_distmat_options(void* h, const int* runtosmpl, int runs, const double* sizes) {
+    dm* d = (dm*)h;
+    if (runtosmpl) {
+        d->runs = runs;
+        d->runtosmpl = (int*)malloc(sizeof(int) * (size_t)runs);
+        memcpy(d->runtosmpl, runtosmpl, sizeof(int) * (size_t)runs);
+    }
+    if (sizes) {   /* :585-611 */
+        d->nfactor = (double*)malloc(sizeof(double) * (size_t)d->smpls);
+        d->prenormlog = (double**)calloc((size_t)d->smpls, sizeof(double*));
+        d->prenormsqrt = (double**)calloc((size_t)d->smpls, sizeof(double*));
+        for (int i = 0; i < d->smpls; ++i) {
+            d->nfactor[i] = (double)1 / sizes[i];
+            d->prenormlog[i] = (double*)malloc(PRECMP * sizeof(double));
+            d->prenormsqrt[i] = (double*)malloc(PRECMP * sizeof(double));
+            for (int j = 0; j < PRECMP; ++j) {
+                d->prenormlog[i][j] = log((double)j * d->nfactor[i] + 1);
+                d->prenormsqrt[i][j] = sqrt((double)j * d->nfactor[i]);
+            }
+        }
+    }
+    return 0;
+}
 
 #define OFF(d, x, y, z) ((size_t)(x) * (d)->smpls * (d)->smpls + (size_t)(y) * (d)->smpls + (z))
 
@@ -83,8 +119,9 @@ int orc_distmat_add(void* h, const unsigned* ids, const unsigned long long* freq
     memset(freq, 0, sizeof(unsigned) * (size_t)smpls);
     for (unsigned q = 0; q < npairs; ++q) {           /* parse(), :84-125 */
         unsigned run = ids[q], frq = (unsigned)freqs[q];
-        if (run >= (unsigned)smpls) return -2;
+        if (run >= (unsigned)d->runs) return -2;
         if (frq < d->minfreq) continue;
+        if (d->runtosmpl) run = (unsigned)d->runtosmpl[run];
         samples[l++] = run;
         freq[run] = frq;
     }
@@ -99,16 +136,27 @@ int orc_distmat_add(void* h, const unsigned* ids, const unsigned long long* freq
         }
         uniq = j + 1;
     }
-    /* entropy(), :128-145 */
-    unsigned sumN = (unsigned)smpls;
-    double sumNlogN = 0;
-    for (unsigned i = 0; i < uniq; ++i) {
-        unsigned frq = freq[samples[i]];
-        sumN += frq;
-        sumNlogN += (double)(frq + 1) * log(frq + 1) / log(2);
+    double entr;
+    if (d->nfactor) {   /* normalized_entropy(), :147-165 */
+        double sumN = (double)smpls, sumNlogN = 0;
+        for (unsigned i = 0; i < uniq; ++i) {
+            double frq = (double)freq[samples[i]] * d->nfactor[samples[i]];
+            sumN += frq;
+            sumNlogN += (frq + 1) * log(frq + 1) / log(2);
+        }
+        double entropy = (log(sumN) / log(2) - sumNlogN / sumN);
+        entr = log(2) * entropy / log(smpls);
+    } else {            /* entropy(), :128-145 */
+        unsigned sumN = (unsigned)smpls;
+        double sumNlogN = 0;
+        for (unsigned i = 0; i < uniq; ++i) {
+            unsigned frq = freq[samples[i]];
+            sumN += frq;
+            sumNlogN += (double)(frq + 1) * log(frq + 1) / log(2);
+        }
+        double entropy = (log(sumN) / log(2) - sumNlogN / (double)sumN);
+        entr = log(2) * entropy / log(smpls);
     }
-    double entropy = (log(sumN) / log(2) - sumNlogN / (double)sumN);
-    double entr = log(2) * entropy / log(smpls);
     int bucket = -1;
     for (int i = d->nm; i > 0;) {                      /* :690-703 */
         --i;
@@ -123,6 +171,15 @@ int orc_distmat_add(void* h, const unsigned* ids, const unsigned long long* freq
             for (int k = j + 1; k < smpls; ++k)
                 if (freq[j] || freq[k]) {
                     cell* c = &M[OFF(d, bucket, j, k)];
+                    if (d->nfactor) {   /* add_normalized(), :199-228 (lgamma disabled there) */
+                        if (freq[j] < PRECMP && freq[k] < PRECMP) {
+                            c->lg += pow(d->prenormlog[j][freq[j]] - d->prenormlog[k][freq[k]], 2);
+                            c->sq += pow(d->prenormsqrt[j][freq[j]] - d->prenormsqrt[k][freq[k]], 2);
+                        } else {
+                            c->lg += pow(log(1 + (double)freq[j] * d->nfactor[j]) - log(1 + (double)freq[k] * d->nfactor[k]), 2);
+                            c->sq += pow(sqrt((double)freq[j] * d->nfactor[j]) - sqrt((double)freq[k] * d->nfactor[k]), 2);
+                        }
+                    } else
                     if (freq[j] < PRECMP && freq[k] < PRECMP) {
                         c->lg += pow(prelog[freq[j]] - prelog[freq[k]], 2);
                         c->sq += pow(presqrt[freq[j]] - presqrt[freq[k]], 2);

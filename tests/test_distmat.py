@@ -29,6 +29,7 @@ def _olib():
     L.orc_distmat_add_text.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.orc_distmat_finish.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4 + [C.c_void_p] * 5
     L.orc_distmat_steps.argtypes = [C.c_double, C.c_void_p, C.c_int]
+    L.orc_distmat_options.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_free_text.argtypes = [C.c_void_p]
     return L
 
@@ -45,14 +46,19 @@ def case_input(setname, case):
         buf = (C.c_double * 256)()
         n = _olib().orc_distmat_steps(float(args[args.index("-e") + 1]), buf, 256)
         maxent = list(buf[:n])
-    return text, len(MAN["sets"][setname]["names"]), maxent, minfreq
+    mapping, sizes = info.get("mapping"), info.get("sizes")
+    smpls = max(mapping) + 1 if mapping else len(MAN["sets"][setname]["names"])
+    return text, smpls, maxent, minfreq, mapping, sizes
 
 
-def oracle_run(text, smpls, maxent, minfreq):
+def oracle_run(text, smpls, maxent, minfreq, mapping=None, sizes=None):
     L = _olib()
     me = (C.c_double * len(maxent))(*maxent)
     h = L.orc_distmat_new(smpls, me, len(maxent), minfreq)
     assert h
+    mp = (C.c_int * len(mapping))(*mapping) if mapping else None
+    sz = (C.c_double * len(sizes))(*sizes) if sizes else None
+    L.orc_distmat_options(h, mp, len(mapping) if mapping else 0, sz)
     rows = L.orc_distmat_add_text(h, text, len(text))
     assert rows == text.count(b"\n")
     outs = [C.c_void_p() for _ in range(4)]
@@ -70,8 +76,8 @@ def oracle_run(text, smpls, maxent, minfreq):
 
 @pytest.mark.parametrize("setname,case", CASES)
 def test_oracle_reproduces_reference_tool_output(setname, case):
-    text, smpls, maxent, minfreq = case_input(setname, case)
-    texts, nout, cnt, mats = oracle_run(text, smpls, maxent, minfreq)
+    text, smpls, maxent, minfreq, mapping, sizes = case_input(setname, case)
+    texts, nout, cnt, mats = oracle_run(text, smpls, maxent, minfreq, mapping, sizes)
     for kind, got in zip(("count", "log", "sqrt", "lgamma"), texts):
         want = gzip.open(os.path.join(GOLD, setname, "distmat.%s.%s.gz" % (case, kind)), "rb").read()
         assert got == want, (setname, case, kind)
@@ -96,9 +102,9 @@ def _cmp(res, nout, cnt, mats):
 @pytest.mark.gpu
 @pytest.mark.parametrize("setname,case", CASES)
 def test_gpu_distmat_matches_oracle_on_goldens(setname, case, pydsm_mod):
-    text, smpls, maxent, minfreq = case_input(setname, case)
-    texts, nout, cnt, mats = oracle_run(text, smpls, maxent, minfreq)
-    with pydsm_mod.DistMat(smpls, maxent=maxent, minfreq=minfreq) as dm:
+    text, smpls, maxent, minfreq, mapping, sizes = case_input(setname, case)
+    texts, nout, cnt, mats = oracle_run(text, smpls, maxent, minfreq, mapping, sizes)
+    with pydsm_mod.DistMat(smpls, maxent=maxent, minfreq=minfreq, run_to_sample=mapping, sizes=sizes) as dm:
         half = text.rfind(b"\n", 0, len(text) // 2) + 1
         dm.add_text(text[:half])          # two batches: accumulation across calls
         dm.add_text(text[half:])
@@ -160,7 +166,7 @@ def test_cli_dropin_writes_the_tools_files(tmp_path):
     """smtxt2entropy_hip with the reference's options: the count file is byte-identical to the reference tool's, the double
     files agree to the printed precision; an existing output file is refused like the tool does."""
     exe = os.path.join(ROOT, "dsm-framework_amd", "host", "smtxt2entropy_hip")
-    text, smpls, maxent, minfreq = case_input("five", "minfreq")
+    text, smpls, maxent, minfreq, _, _ = case_input("five", "minfreq")
     args = [exe, "-s", str(smpls), "-m", ",".join(str(x) for x in maxent), "-M", str(minfreq), "-F", "o"]
     r = subprocess.run(args, input=text, cwd=tmp_path, capture_output=True)
     assert r.returncode == 0, r.stderr
@@ -177,7 +183,29 @@ def test_cli_dropin_writes_the_tools_files(tmp_path):
     r = subprocess.run(args, input=text, cwd=tmp_path, capture_output=True)
     assert r.returncode == 1 and b"already exists" in r.stderr
     # -e steps
-    text, smpls, maxent, _ = case_input("toy3", "step")
+    text, smpls, maxent, _, _, _ = case_input("toy3", "step")
     r = subprocess.run([exe, "-s", str(smpls), "-e", "0.3", "-F", "s"], input=text, cwd=tmp_path, capture_output=True)
     assert r.returncode == 0, r.stderr
     assert open(os.path.join(tmp_path, "count.s"), "rb").read() == gzip.open(os.path.join(GOLD, "toy3", "distmat.step.count.gz"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_samplefile_and_normalize(tmp_path):
+    """-S and -N through the drop-in CLI, files in the tool's formats."""
+    exe = os.path.join(ROOT, "dsm-framework_amd", "host", "smtxt2entropy_hip")
+    text, smpls, maxent, minfreq, mapping, sizes = case_input("five", "smap_norm")
+    open(os.path.join(tmp_path, "map.txt"), "w").write("".join("%d\n" % x for x in mapping))
+    open(os.path.join(tmp_path, "sizes.txt"), "w").write("".join("d%d\t%r\n" % (i, x) for i, x in enumerate(sizes)))
+    r = subprocess.run([exe, "-S", "map.txt", "-N", "sizes.txt", "-e", "0.5", "-F", "o"], input=text, cwd=tmp_path, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    for kind in ("count", "log", "sqrt", "lgamma"):
+        got = open(os.path.join(tmp_path, kind + ".o"), "rb").read()
+        want = gzip.open(os.path.join(GOLD, "five", "distmat.smap_norm.%s.gz" % kind), "rb").read()
+        if kind in ("count", "lgamma"):      # lgamma stays zero under -N
+            assert got == want, kind
+        else:
+            for a, b in zip(got.split(), want.split()):
+                if a != b:
+                    assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b))) + 2e-6, (kind, a, b)
+    r = subprocess.run([exe, "-s", "3", "-S", "map.txt", "-m", "1.0", "-F", "x"], input=text, cwd=tmp_path, capture_output=True)
+    assert r.returncode == 1
