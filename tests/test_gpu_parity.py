@@ -345,3 +345,33 @@ def test_index_residency_offload_and_reload(golden, pydsm_mod):
     k.close()
     for ix in idx:
         ix.close()
+
+
+def test_seventy_and_273_samples_against_oracle(pydsm_mod, tmp_path):
+    """More than 64 samples take the widest order kernel (reader sets rehash up to 541 buckets) and, for the distance matrices,
+    the global-atomic path; 273 is the reference's MAX_READERS.  Small synthetic samples from one genome, oracle as judge."""
+    from pydsm import builder
+    rng = np.random.default_rng(11)
+    genome = rng.integers(0, 4, 1500)
+    for d, fmin, pfx in ((70, 2, ["A", "GT"]), (273, 2, ["C"])):
+        paths = []
+        for s in range(d):
+            starts = rng.integers(0, len(genome) - 40, 60)
+            codes = np.stack([genome[a:a + 40] for a in starts]).astype(np.uint8)
+            flip = rng.random(codes.shape) < 0.01
+            codes = np.where(flip, (codes + rng.integers(1, 4, codes.shape)) % 4, codes).astype(np.uint8)
+            p = tmp_path / ("s%03d_%d.fasta.fmi" % (s, d))
+            import torch
+            builder.build_from_codes(torch.from_numpy(codes), str(p))
+            paths.append(str(p))
+        idx = [pydsm_mod.Index(p) for p in paths]
+        oidx = [orc.Index(p) for p in paths]
+        names = [ix.name for ix in idx]
+        kw = dict(fmin=fmin, maxdepth=12, pmin=1, emax=9.0)  # pmin 1: the reference server desynchronises on single-reader nodes above depth 7 otherwise
+        for p in pfx:
+            got, st = pydsm_mod.mine(idx, p, **kw)
+            want, ost = orc.mine(oidx, names, [p], threads=4, **kw)
+            assert got == want, (d, p)
+            assert st.pair_order_exact == 1 and st.tuples == ost[4] and st.tuples > 100
+        for ix in idx + oidx:
+            ix.close()
