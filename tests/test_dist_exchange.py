@@ -244,6 +244,14 @@ def test_bench_forced_exchange_rehearsal_on_rccl(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     a, b = outs
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):            # the driver's contract for the JSON line
+        assert k in a, k
+    assert a["n_gpus"] == 1 and a["scaling"] == "weak" and a["higher_is_better"] is True and a["vs_baseline"] is None
+    assert "workload" in a["config"] and a["dtype"] in ("u32", "u64") and a["data"] == "synthetic"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in a["roofline"], k
+    assert a["roofline"]["bound"] == "hbm" and abs(a["roofline"]["frac"] - a["roofline"]["achieved"] / a["roofline"]["peak"]) < 1e-9
     assert b["config"]["parallelism"].endswith("2 prefix lane(s) per GPU")
     for k in ("rank0_nodes_per_step", "tuples_per_step", "union_nodes_per_step", "candidates_per_step", "rank_ops_per_node"):
         assert a["detail"][k] == b["detail"][k], k
