@@ -1,0 +1,65 @@
+"""Host logic without a GPU: the server-side decoder of client wire streams (csrc/stream_parse.h: TrieReader's token rules,
+ServerSocket's varint, the R checksums) on the committed reference streams, and its rejection of damaged ones."""
+import os
+import subprocess
+
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("native") / "stream_parse_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-o", out,
+                    os.path.join(ROOT, "tests", "native", "stream_parse_check.cpp")], check=True)
+    return out
+
+
+def _run(exe, tmp_path, body):
+    p = tmp_path / "s.bin"
+    p.write_bytes(body)
+    r = subprocess.run([exe, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout.decode().strip(), r.stderr.decode()
+
+
+def _body(stream):
+    return stream[stream.index(b".") + 1:]      # drop 'S' name '.'
+
+
+def test_reference_streams_parse_and_count(golden, exe, tmp_path):
+    names = golden.manifest["sets"]["toy3"]["names"]
+    sigs = set()
+    for name in names:
+        o = orc.Index(golden.fmi("toy3", name))
+        for prefix in ("A", "GT", "TTG", "ACGTACGTACGT"):
+            stream = golden.stream("toy3", name, prefix)
+            rc, out, err = _run(exe, tmp_path, _body(stream))
+            assert rc == 0 and out.startswith("ok "), (out, err)
+            fields = dict(kv.split("=") for kv in out.split()[1:])
+            _, (reported, _, _) = o.enumerate(name, prefix, fmin=2)
+            assert int(fields["nodes"]) == reported                                 # the client's own count of '(' tokens
+            assert int(fields["stored"]) == reported + 1                       # plus the root
+            sigs.add(fields["sig"])
+        o.close()
+    assert len(sigs) > 6
+    rc, out, _ = _run(exe, tmp_path, b"")                                      # a client that found nothing
+    assert rc == 0 and "nodes=0" in out
+
+
+def test_damaged_streams_are_rejected(golden, exe, tmp_path):
+    name = golden.manifest["sets"]["toy3"]["names"][0]
+    body = _body(golden.stream("toy3", name, "GT"))
+    assert _run(exe, tmp_path, body)[0] == 0
+    i = body.index(b"R")
+    for bad in (body[:-1],                                   # truncated: the last ')' is missing
+                body[: len(body) // 2],                      # cut in the middle
+                body[:i + 1] + bytes([body[i + 1] ^ 1]) + body[i + 2:],   # wrong R checksum (TrieReader.h:86-95)
+                body.replace(b"(G", b"(X", 1),               # not a DNA byte (TrieReader.h:58-63)
+                b")" + body,
+                body + b"(A"):
+        rc, out, err = _run(exe, tmp_path, bad)
+        assert rc == 1 and out.startswith("error:"), (out, err)
+        assert "AddressSanitizer" not in err and "runtime error" not in err
