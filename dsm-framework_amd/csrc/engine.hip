@@ -1708,7 +1708,9 @@ class Engine {
                 DSM_HIP(hipMemcpyAsync(order16[0], ro.data(), (size_t)d * sizeof(u16), hipMemcpyHostToDevice, st));
             }
         }
-        const u32 order_mode = d < 2 ? 0u : (d <= 13 ? 1u : 2u);  // (declared before the level loop: used by seed/capture)
+        // pmax == 1 (sample-specific substrings, BASELINE configs[4]): every printed node has one reader, its single pair needs no
+        // order, and nothing else depends on the reader sets' iteration orders -- the order kernels are skipped altogether
+        const u32 order_mode = (d < 2 || prm.pmax == 1) ? 0u : (d <= 13 ? 1u : 2u);  // (declared before the level loop: used by seed/capture)
         stats.pair_order_exact = 1;
 
         // Width of the frequency column of the level about to be exchanged.  Every rank derives it from the same number: the

@@ -373,5 +373,9 @@ def test_seventy_and_273_samples_against_oracle(pydsm_mod, tmp_path):
             want, ost = orc.mine(oidx, names, [p], threads=4, **kw)
             assert got == want, (d, p)
             assert st.pair_order_exact == 1 and st.tuples == ost[4] and st.tuples > 100
+            kw1 = dict(kw, pmax=1)      # sample-specific substrings: the order kernels are skipped (single readers need no order)
+            got, st = pydsm_mod.mine(idx, p, **kw1)
+            want, ost = orc.mine(oidx, names, [p], threads=4, **kw1)
+            assert got == want and st.tuples == ost[4], (d, p, "pmax=1")
         for ix in idx + oidx:
             ix.close()
