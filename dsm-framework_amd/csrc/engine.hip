@@ -658,7 +658,8 @@ __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, cons
     const u16* ord = order + (size_t)u * x.d;
     u8 mask[MAXD];
     u16 ins[4][MAXD];
-    u16 loc[MAXD], tmp[MAXD];
+    u16 loc[MAXD];
+    u16 work[MAXD + (MAXD <= 127 ? 127 : 541)];  // so_work_size(MAXD, MAXD): next pointers by id, bucket table
     u32 icnt[4] = {0, 0, 0, 0};
     for (u32 k = 0; k < cnt; ++k) {  // round 1: every reader of the parent reads its first child
         const u32 r = ord[k];
@@ -669,7 +670,7 @@ __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, cons
     u32 v = firstchild[u];
     for (int i = 0; i < 4; ++i) {
         if (!icnt[i]) continue;
-        set_iteration_order(ins[i], icnt[i], loc, tmp);
+        set_iteration_order(ins[i], icnt[i], loc, work, (u32)MAXD);
         u16* dst = order_next + (size_t)v * x.d;
         for (u32 k = 0; k < icnt[i]; ++k) dst[k] = loc[k];
         ++v;
@@ -1697,9 +1698,9 @@ class Engine {
             u16 rootT = (u16)d;
             DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
             // root reader set: ids inserted 0..d-1 (metaserver.cpp:736-739)
-            std::vector<u16> seq(d), ro(d + 1), tmp(d + 1);
+            std::vector<u16> seq(d), ro(d + 1), tmp(so_work_size(d, d));
             for (u32 k = 0; k < d; ++k) seq[k] = (u16)k;
-            set_iteration_order(seq.data(), d, ro.data(), tmp.data());
+            set_iteration_order(seq.data(), d, ro.data(), tmp.data(), d);
             if (d <= 13) {
                 u64 ord = 0;
                 for (u32 k = 0; k < d; ++k) ord |= (u64)ro[k] << (4 * k);

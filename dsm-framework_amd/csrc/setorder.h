@@ -2,7 +2,7 @@
 // distinct insertions into a default-constructed set.  metaserver keeps its reader sets in that container
 // (metaserver.cpp:23) and prints / sums in its iteration order, so the order is part of bit-exact parity.
 //
-// Model (libstdc++ _Hashtable with _Prime_rehash_policy, max load factor 1):
+// Model (libstdc++ _Hashtable with _Prime_rehash_policy, max load factor 1), replayed with the container's own data structure:
 //   * one singly linked list of all nodes; the nodes of a bucket are contiguous in it;
 //   * inserting key k: if bucket k % B is non-empty the node goes to the FRONT of that bucket's run, otherwise to
 //     the front of the whole list;
@@ -21,33 +21,58 @@
 
 namespace dsm {
 
-DSM_HD inline uint32_t so_place(uint16_t* L, uint32_t s, uint32_t B, uint16_t k) {
-    const uint32_t b = k % B;
-    uint32_t p = 0;
-    for (uint32_t i = 0; i < s; ++i)
-        if (L[i] % B == b) { p = i; break; }
-    for (uint32_t i = s; i > p; --i) L[i] = L[i - 1];
-    L[p] = k;
-    return s + 1;
-}
-
 DSM_HD inline uint32_t so_next_buckets(uint32_t size_after) {  // bucket count in force once `size_after` keys are in
     return size_after <= 13 ? 13u : size_after <= 29 ? 29u : size_after <= 59 ? 59u : size_after <= 127 ? 127u : size_after <= 257 ? 257u : 541u;
 }
 
-// out[0..m) = iteration order after inserting seq[0..m) (distinct keys < 541); tmp needs m entries.
-DSM_HD inline void set_iteration_order(const uint16_t* seq, uint32_t m, uint16_t* out, uint16_t* tmp) {
-    uint32_t s = 0, B = 1;
+// The container as it is: a singly linked list threaded through nxt[key] plus, per bucket, the node BEFORE the bucket's
+// first node (_Hashtable::_M_buckets; SO_HEAD stands for _M_before_begin).  O(1) per insertion, O(size + buckets) per rehash.
+constexpr uint16_t SO_HEAD = 0xFFFF, SO_NIL = 0xFFFE, SO_EMPTY = 0xFFFD;
+
+// work space of set_iteration_order: nxt[max key + 1] followed by before[so_next_buckets(m)]
+DSM_HD inline uint32_t so_work_size(uint32_t key_limit, uint32_t m) { return key_limit + so_next_buckets(m); }
+
+// _M_insert_bucket_begin (hashtable.h): front of the bucket's run, or front of the whole list for an empty bucket
+DSM_HD inline void so_insert(uint16_t* nxt, uint16_t* before, uint32_t B, uint16_t& first, uint16_t k) {
+    const uint32_t b = k % B;
+    const uint16_t prev = before[b];
+    if (prev != SO_EMPTY) {
+        uint16_t& slot = prev == SO_HEAD ? first : nxt[prev];
+        nxt[k] = slot;
+        slot = k;
+    } else {
+        nxt[k] = first;
+        first = k;
+        if (nxt[k] != SO_NIL) before[nxt[k] % B] = k;
+        before[b] = SO_HEAD;
+    }
+}
+
+// out[0..m) = iteration order after inserting seq[0..m) (distinct keys < key_limit <= 541);
+// work needs so_work_size(key_limit, m) entries.
+DSM_HD inline void set_iteration_order(const uint16_t* seq, uint32_t m, uint16_t* out, uint16_t* work, uint32_t key_limit) {
+    uint16_t* nxt = work;
+    uint16_t* before = work + key_limit;
+    uint16_t first = SO_NIL;
+    uint32_t B = 1;
+    before[0] = SO_EMPTY;
     for (uint32_t t = 0; t < m; ++t) {
         const uint32_t nb = so_next_buckets(t + 1);
-        if (nb != B) {  // rehash before the insertion that crosses the threshold
-            for (uint32_t i = 0; i < s; ++i) tmp[i] = out[i];
-            uint32_t s2 = 0;
-            for (uint32_t i = 0; i < s; ++i) s2 = so_place(out, s2, nb, tmp[i]);
+        if (nb != B) {  // _M_rehash_aux(unique keys) before the insertion that crosses the threshold: re-insert in list order
+            for (uint32_t i = 0; i < nb; ++i) before[i] = SO_EMPTY;
+            uint16_t p = first;
+            first = SO_NIL;
+            while (p != SO_NIL) {
+                const uint16_t nx = nxt[p];
+                so_insert(nxt, before, nb, first, p);
+                p = nx;
+            }
             B = nb;
         }
-        s = so_place(out, s, B, seq[t]);
+        so_insert(nxt, before, B, first, seq[t]);
     }
+    uint32_t i = 0;
+    for (uint16_t p = first; p != SO_NIL; p = nxt[p]) out[i++] = p;
 }
 
 }  // namespace dsm

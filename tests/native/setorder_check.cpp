@@ -16,10 +16,10 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> ids(d);
         for (unsigned i = 0; i < d; ++i) ids[i] = (uint16_t)i;
         if (t % 3) std::shuffle(ids.begin(), ids.end(), rng);          // every third trial inserts 0..m-1 in order (the root set)
-        std::vector<uint16_t> seq(ids.begin(), ids.begin() + m), out(m + 1), tmp(m + 1);
+        std::vector<uint16_t> seq(ids.begin(), ids.begin() + m), out(m + 1), tmp(dsm::so_work_size(d, m));
         std::unordered_set<unsigned> s;
         for (auto k : seq) s.insert(k);
-        dsm::set_iteration_order(seq.data(), m, out.data(), tmp.data());
+        dsm::set_iteration_order(seq.data(), m, out.data(), tmp.data(), d);
         unsigned i = 0;
         for (auto it = s.begin(); it != s.end(); ++it, ++i)
             if (*it != out[i]) { printf("MISMATCH trial %d d=%u m=%u at %u: real %u model %u\n", t, d, m, i, *it, out[i]); return 1; }
