@@ -184,7 +184,7 @@ def main():
         if nlanes > 1:  # split what is left between the lanes still to be created (and the ranks sharing this card)
             free_b, _ = torch.cuda.mem_get_info(dev)
             sharing = (world + ndev - 1) // max(1, ndev)
-            want = (256 << 20) + 900 * sum(x.n for x in ixs) * world
+            want = (256 << 20) + 64 * sum(x.n for x in ixs) * world
             arena = int(min(want, free_b * 0.7 / (nlanes - j) / sharing))
         lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
                                     allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,

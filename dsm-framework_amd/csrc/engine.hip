@@ -1482,7 +1482,10 @@ class Engine {
         const u64 fbound = (world > 1 ? (u64)d * nmax : nsum) + 16;
         u64 budget = p.arena_bytes ? p.arena_bytes : (u64)(free_b * 0.7);
         if (!p.arena_bytes) {
-            u64 want = (256ull << 20) + 900ull * nsum * (u64)world;
+            // 32 bytes per indexed symbol: at 20x coverage a one-letter prefix needs about 12 (frontier buffers for 1.2 % of n
+            // nodes, retained level arrays for 0.35 n nodes); a prefix that does not fit is split automatically.  Very large
+            // allocations are slow to create (a 190 GB arena takes 4-7 s, 40 GB no measurable time).
+            u64 want = (256ull << 20) + 32ull * nsum * (u64)world;
             if (want < budget) budget = want;
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
