@@ -131,7 +131,11 @@ def main():
     if forced:
         os.environ["DSM_FORCE_EXCHANGE"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        if "MASTER_PORT" not in os.environ:  # any free port: this world of one talks to nobody
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group(os.environ.get("DSM_BENCH_BACKEND", "nccl"), rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
