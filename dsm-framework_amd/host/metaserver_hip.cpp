@@ -14,6 +14,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -83,6 +84,9 @@ int main(int argc, char** argv) {
     std::vector<std::vector<uint8_t>> streams(d);
     std::vector<bool> seen(d, false);
     std::vector<std::thread> readers;
+    std::vector<dsm_trie*> tries(d, nullptr);
+    std::string perr;
+    std::mutex err_mu;
     size_t pending = d;
     while (pending) {  // metaserver.cpp:682-728: handshake 'S' name '.', then the node stream until EOF
         int fd = accept(sock, nullptr, nullptr);
@@ -102,7 +106,7 @@ int main(int argc, char** argv) {
         seen[id] = true;
         --pending;
         if (verbose) std::cerr << "new connection id = " << id << ", name = " << name << " (" << pending << " pending)" << std::endl;
-        readers.emplace_back([fd, id, &streams] {
+        readers.emplace_back([fd, id, device, &streams, &tries, &perr, &err_mu] {
             std::vector<uint8_t>& s = streams[id];
             std::vector<uint8_t> buf(1 << 20);
             for (;;) {
@@ -111,19 +115,17 @@ int main(int argc, char** argv) {
                 s.insert(s.end(), buf.begin(), buf.begin() + r);
             }
             close(fd);
+            // decode right here: the streams of the samples are parsed side by side (the decoder is single-threaded per stream)
+            if (dsm_trie_parse(s.data(), s.size(), device, &tries[id])) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (perr.empty()) perr = std::string(dsm_last_error()) + " (reader " + std::to_string(id) + ")";
+            }
+            std::vector<uint8_t>().swap(s);
         });
     }
     for (auto& t : readers) t.join();
     close(sock);
-
-    std::vector<dsm_trie*> tries(d, nullptr);
-    for (size_t k = 0; k < d; ++k) {
-        if (dsm_trie_parse(streams[k].data(), streams[k].size(), device, &tries[k])) {
-            std::cerr << "error: " << dsm_last_error() << " (reader " << k << ")" << std::endl;
-            return 1;
-        }
-        std::vector<uint8_t>().swap(streams[k]);
-    }
+    if (!perr.empty()) { std::cerr << "error: " << perr << std::endl; return 1; }
     dsm_stats st;
     if (dsm_merge(tries.data(), (int)d, &p, print_batch, nullptr, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
     fflush(stdout);
