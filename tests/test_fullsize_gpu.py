@@ -192,3 +192,36 @@ def test_reload_time_of_a_full_size_index(big):
     print("reload of %.2f GB: %.1f ms = %.1f GB/s" % (ix.device_bytes() / 1e9, dt * 1e3, ix.device_bytes() / dt / 1e9))
     assert ix.check() == ix.n
     assert dt < 2.0
+
+
+def test_two_full_size_samples_against_oracle(big):
+    """d = 2 at BASELINE's per-sample size (two 10^7-read sets on one card, the second with 5 % private sequence): random
+    8-mer prefixes and a whole one-letter prefix restricted by maxdepth, tuples and counters equal the oracle's."""
+    import torch
+    import orc
+    from pydsm import builder
+    pydsm, ix0, path0, reads = big
+    d = os.path.dirname(path0)
+    path1 = os.path.join(d, "sample-1.s43_r%d_l100_g%d_e0.005_p0.05.fmi" % (reads, reads * 5))
+    if not os.path.exists(path1):
+        codes = builder.synth_reads(43, reads, 100, reads * 5, 0.005, device="cuda", private_frac=0.05)
+        builder.build_from_codes(codes, path1 + ".tmp")
+        del codes
+        torch.cuda.empty_cache()
+        os.replace(path1 + ".tmp", path1)
+    ix1 = pydsm.Index(path1)
+    o0, o1 = orc.Index(path0), orc.Index(path1)
+    names = [ix0.name, ix1.name]
+    rng = np.random.default_rng(77)
+    with pydsm.Miner([ix0, ix1], fmin=10, pmin=1, emax=2.0) as m1, pydsm.Miner([ix0, ix1], fmin=10, pmin=2, emax=1.0, emin=0.05) as m2:
+        for _ in range(4):
+            p = "".join(rng.choice(list("ACGT"), 8))
+            for m, kw in ((m1, dict(fmin=10, pmin=1, emax=2.0)), (m2, dict(fmin=10, pmin=2, emax=1.0, emin=0.05))):
+                got, st = m.mine(p)
+                want, ost = orc.mine([o0, o1], names, [p], threads=4, **kw)
+                assert got == want, (p, kw)
+                assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (p, kw)
+    got, st = pydsm.mine([ix0, ix1], "G", fmin=10, maxdepth=11, pmin=1, emax=2.0)
+    want, ost = orc.mine([o0, o1], names, ["G"], fmin=10, maxdepth=11, pmin=1, emax=2.0, threads=8)
+    assert got == want and st.tuples == ost[4] and st.max_frontier > 1000000
+    ix1.close(); o0.close(); o1.close()
