@@ -100,7 +100,8 @@ def _gpu_worker(rank, world, port, q, fmis, prefixes, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("setname,world,cfg", [("toy3", 3, "default"), ("five", 5, "default"), ("toy3", 3, "pmax2")])
+@pytest.mark.parametrize("setname,world,cfg", [("toy3", 3, "default"), ("five", 5, "default"), ("toy3", 3, "pmax2"),
+                                                ("many30", 5, "p3")])   # 5 ranks x 6 samples: several samples per rank, d = 30
 def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cfg):
     import orc
     from goldenlib import server_args_to_kw
@@ -109,7 +110,9 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
     fmis = [golden.fmi(setname, n) for n in names]
     kw = server_args_to_kw(m["server_cfgs"][cfg])
     kw["fmin"] = m["fmin"]
-    prefixes = ["A", "GT"] if setname == "toy3" else ["C"]
+    if "maxdepth" in m:
+        kw["maxdepth"] = m["maxdepth"]
+    prefixes = ["A", "GT"] if setname == "toy3" else (["AC", "G"] if setname == "many30" else ["C"])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -140,7 +143,7 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
         assert splits[0] > 0, "the tiny budget was meant to force prefix splits"
     oidx = [orc.Index(f) for f in fmis]
     for p in prefixes:
-        want = sum(ix.enumerate(n, p, fmin=m["fmin"])[1][0] for ix, n in zip(oidx, names))
+        want = sum(ix.enumerate(n, p, fmin=m["fmin"], maxdepth=m.get("maxdepth", 0xFFFFFFFF))[1][0] for ix, n in zip(oidx, names))
         assert sum(reported[p]) == want
 
 
