@@ -44,6 +44,11 @@ def test_no_cpu_fallback_without_gpu(golden):
     with pytest.raises(pydsm.DsmError) as e:
         pydsm.Index(golden.fmi("toy3", "toy-1"))
     assert e.value.code == -19  # DSM_E_NODEV
+    with pytest.raises(pydsm.DsmError) as e:     # the distance matrices have no CPU path either
+        pydsm.DistMat(3, maxent=[1.0])
+    assert e.value.code == -19
+    with pytest.raises(pydsm.DsmError):          # nor the server-side merge
+        pydsm.Trie(b"")
 
 
 def test_open_errors_are_reported_not_fatal(tmp_path):
