@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 #include "common.h"
 #include "scan.h"
@@ -652,32 +653,34 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
 template <typename P, int MAXD>
 __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u16* __restrict__ order, const u32* __restrict__ firstchild,
                                  u16* __restrict__ order_next) {
+    // per-thread working set in scratch: byte-sized ids when they fit (at most 64 samples: 575 B instead of 1.1 KB)
+    typedef typename std::conditional<(MAXD <= 250), u8, u16>::type K;
     u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= F) return;
     const u32 cnt = nT[u];
     const u16* ord = order + (size_t)u * x.d;
     u8 mask[MAXD];
-    u16 ins[4][MAXD];
-    u16 loc[MAXD];
-    u16 work[MAXD + (MAXD <= 127 ? 127 : 541)];  // so_work_size(MAXD, MAXD): next pointers by id, bucket table
+    K ins[4][MAXD];
+    K loc[MAXD];
+    K work[MAXD + (MAXD <= 127 ? 127 : 541)];  // so_work_size(MAXD, MAXD): next pointers by id, bucket table
     u32 icnt[4] = {0, 0, 0, 0};
     for (u32 k = 0; k < cnt; ++k) {  // round 1: every reader of the parent reads its first child
         const u32 r = ord[k];
         u32 m = x_pl<P>(x, r, u) & 15u;
         mask[r] = (u8)m;
-        if (m) { int f = __ffs(m) - 1; ins[f][icnt[f]++] = (u16)r; }
+        if (m) { int f = __ffs(m) - 1; ins[f][icnt[f]++] = (K)r; }
     }
     u32 v = firstchild[u];
     for (int i = 0; i < 4; ++i) {
         if (!icnt[i]) continue;
-        set_iteration_order(ins[i], icnt[i], loc, work, (u32)MAXD);
+        set_iteration_order<K>(ins[i], icnt[i], loc, work, (u32)MAXD);
         u16* dst = order_next + (size_t)v * x.d;
-        for (u32 k = 0; k < icnt[i]; ++k) dst[k] = loc[k];
+        for (u32 k = 0; k < icnt[i]; ++k) dst[k] = (u16)loc[k];
         ++v;
         for (u32 k = 0; k < icnt[i]; ++k) {  // next round: this child's readers, in its iteration order
             const u32 r = loc[k];
             u32 m = mask[r] & ~((2u << i) - 1);
-            if (m) { int g = __ffs(m) - 1; ins[g][icnt[g]++] = (u16)r; }
+            if (m) { int g = __ffs(m) - 1; ins[g][icnt[g]++] = (K)r; }
         }
     }
 }
@@ -1703,7 +1706,7 @@ class Engine {
             // root reader set: ids inserted 0..d-1 (metaserver.cpp:736-739)
             std::vector<u16> seq(d), ro(d + 1), tmp(so_work_size(d, d));
             for (u32 k = 0; k < d; ++k) seq[k] = (u16)k;
-            set_iteration_order(seq.data(), d, ro.data(), tmp.data(), d);
+            set_iteration_order<u16>(seq.data(), d, ro.data(), tmp.data(), d);
             if (d <= 13) {
                 u64 ord = 0;
                 for (u32 k = 0; k < d; ++k) ord |= (u64)ro[k] << (4 * k);

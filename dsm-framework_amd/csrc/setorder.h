@@ -27,52 +27,57 @@ DSM_HD inline uint32_t so_next_buckets(uint32_t size_after) {  // bucket count i
 
 // The container as it is: a singly linked list threaded through nxt[key] plus, per bucket, the node BEFORE the bucket's
 // first node (_Hashtable::_M_buckets; SO_HEAD stands for _M_before_begin).  O(1) per insertion, O(size + buckets) per rehash.
-constexpr uint16_t SO_HEAD = 0xFFFF, SO_NIL = 0xFFFE, SO_EMPTY = 0xFFFD;
+// K = key / link type: uint16_t in general, uint8_t when every key is below 253 (less scratch per thread on the device).
+template <typename K> struct SoMark {
+    static constexpr K HEAD = (K)~(K)0, NIL = (K)(HEAD - 1), EMPTY = (K)(HEAD - 2);
+};
 
 // work space of set_iteration_order: nxt[max key + 1] followed by before[so_next_buckets(m)]
 DSM_HD inline uint32_t so_work_size(uint32_t key_limit, uint32_t m) { return key_limit + so_next_buckets(m); }
 
 // _M_insert_bucket_begin (hashtable.h): front of the bucket's run, or front of the whole list for an empty bucket
-DSM_HD inline void so_insert(uint16_t* nxt, uint16_t* before, uint32_t B, uint16_t& first, uint16_t k) {
+template <typename K>
+DSM_HD inline void so_insert(K* nxt, K* before, uint32_t B, K& first, K k) {
     const uint32_t b = k % B;
-    const uint16_t prev = before[b];
-    if (prev != SO_EMPTY) {
-        uint16_t& slot = prev == SO_HEAD ? first : nxt[prev];
+    const K prev = before[b];
+    if (prev != SoMark<K>::EMPTY) {
+        K& slot = prev == SoMark<K>::HEAD ? first : nxt[prev];
         nxt[k] = slot;
         slot = k;
     } else {
         nxt[k] = first;
         first = k;
-        if (nxt[k] != SO_NIL) before[nxt[k] % B] = k;
-        before[b] = SO_HEAD;
+        if (nxt[k] != SoMark<K>::NIL) before[nxt[k] % B] = k;
+        before[b] = SoMark<K>::HEAD;
     }
 }
 
-// out[0..m) = iteration order after inserting seq[0..m) (distinct keys < key_limit <= 541);
+// out[0..m) = iteration order after inserting seq[0..m) (distinct keys < key_limit <= 541, and < 253 for K = uint8_t);
 // work needs so_work_size(key_limit, m) entries.
-DSM_HD inline void set_iteration_order(const uint16_t* seq, uint32_t m, uint16_t* out, uint16_t* work, uint32_t key_limit) {
-    uint16_t* nxt = work;
-    uint16_t* before = work + key_limit;
-    uint16_t first = SO_NIL;
+template <typename K>
+DSM_HD inline void set_iteration_order(const K* seq, uint32_t m, K* out, K* work, uint32_t key_limit) {
+    K* nxt = work;
+    K* before = work + key_limit;
+    K first = SoMark<K>::NIL;
     uint32_t B = 1;
-    before[0] = SO_EMPTY;
+    before[0] = SoMark<K>::EMPTY;
     for (uint32_t t = 0; t < m; ++t) {
         const uint32_t nb = so_next_buckets(t + 1);
         if (nb != B) {  // _M_rehash_aux(unique keys) before the insertion that crosses the threshold: re-insert in list order
-            for (uint32_t i = 0; i < nb; ++i) before[i] = SO_EMPTY;
-            uint16_t p = first;
-            first = SO_NIL;
-            while (p != SO_NIL) {
-                const uint16_t nx = nxt[p];
-                so_insert(nxt, before, nb, first, p);
+            for (uint32_t i = 0; i < nb; ++i) before[i] = SoMark<K>::EMPTY;
+            K p = first;
+            first = SoMark<K>::NIL;
+            while (p != SoMark<K>::NIL) {
+                const K nx = nxt[p];
+                so_insert<K>(nxt, before, nb, first, p);
                 p = nx;
             }
             B = nb;
         }
-        so_insert(nxt, before, B, first, seq[t]);
+        so_insert<K>(nxt, before, B, first, seq[t]);
     }
     uint32_t i = 0;
-    for (uint16_t p = first; p != SO_NIL; p = nxt[p]) out[i++] = p;
+    for (K p = first; p != SoMark<K>::NIL; p = nxt[p]) out[i++] = p;
 }
 
 }  // namespace dsm

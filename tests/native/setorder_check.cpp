@@ -19,7 +19,13 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> seq(ids.begin(), ids.begin() + m), out(m + 1), tmp(dsm::so_work_size(d, m));
         std::unordered_set<unsigned> s;
         for (auto k : seq) s.insert(k);
-        dsm::set_iteration_order(seq.data(), m, out.data(), tmp.data(), d);
+        dsm::set_iteration_order<uint16_t>(seq.data(), m, out.data(), tmp.data(), d);
+        if (d <= 250) {  // the byte-sized instantiation used on the device for up to 64 samples
+            std::vector<uint8_t> seq8(seq.begin(), seq.end()), out8(m + 1), tmp8(dsm::so_work_size(d, m));
+            dsm::set_iteration_order<uint8_t>(seq8.data(), m, out8.data(), tmp8.data(), d);
+            for (unsigned k = 0; k < m; ++k)
+                if (out8[k] != out[k]) { printf("U8 MISMATCH trial %d\n", t); return 1; }
+        }
         unsigned i = 0;
         for (auto it = s.begin(); it != s.end(); ++it, ++i)
             if (*it != out[i]) { printf("MISMATCH trial %d d=%u m=%u at %u: real %u model %u\n", t, d, m, i, *it, out[i]); return 1; }
