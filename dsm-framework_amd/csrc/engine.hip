@@ -122,18 +122,42 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 // intervals are stored, in base order, in the first popcount(mask) slots: most nodes have one, so the other slots are
 // neither written nor read.  Records are addressed through a handle per frontier node (rp[v]); DEAD = the node is
 // absent from this sample.
+//
+// Order of a level.  The nodes of a level are kept in COLEX order of their paths (sorted by the reversed substring), not in
+// trie order.  The index holds reversed reads, so the suffix-array interval of a substring P is ordered by reverse(P):
+// colex order of the union level IS increasing sp order in every sample.  Neighbouring lanes of the LF-step kernel therefore
+// read neighbouring records and neighbouring (often the same) index blocks, and write neighbouring column entries.
+// LF is monotone, so the children with symbol c of colex-ordered parents are colex-ordered among themselves and every
+// c = A child precedes every c = C child ...: the next level is the stable 4-way partition A|C|G|T of the children, and a
+// child's place is a prefix count over its symbol's bit plane -- no atomics, no allocation that can overflow.
+//   record handle of child (u, c) in a sample = c * seg + 256 * (u / 256) + rank of u among the block's parents with a child c
+// (every block of 256 parents owns 256 handles per symbol: at most one child per symbol and parent).  The trie order the
+// reference prints in is recovered at the end of a prefix from the retained parent links, as before.
 constexpr int REC_FIELDS = 10;
 template <typename P>
 __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
+constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=ext intervals read [5]=records read
 constexpr u32 DEAD = 0xFFFFFFFFu;
-// Child records are allocated per block of 256 parents.  A block reserves a window of ALLOC_WIN handles when it starts, so
-// the atomic's round trip is over long before the count is known; only a block that needs more takes a second, exact
-// allocation (and leaves its window unused).  The counters are spread over up to ALLOC_SHARDS regions of the record
-// buffer, each on its own 128-byte line: one word takes about 9e7 atomics/s, less than the blocks of the deep levels issue.
-constexpr u32 ALLOC_WIN = 320;
-constexpr u32 ALLOC_SHARDS = 32;
-constexpr u32 ALLOC_PITCH = 32;    // u32 per region counter
+constexpr u32 TILE = 256;             // parents per block of the expand / advance kernels
+
+// Children directory of a level ("kids"): per 64 nodes (one wave) four bit planes -- bit j of plane c: node 64w + j has a child
+// with symbol c in the union trie -- and four counts cum[c] = index, in the next level, of the first such child of the wave.
+//   child c of node v = cum[c] + popcount(plane[c] & below(v & 63))
+// 48 bytes per 64 nodes; the lanes of a wave read the same words.
+struct Kids {
+    const u64* plane;  // [4 * waves]
+    const u32* cum;    // [4 * waves]
+};
+__device__ __forceinline__ u32 kid_mask(const Kids& k, u32 v) {
+    const u64* p = k.plane + (size_t)(v >> 6) * 4;
+    const u32 s = v & 63;
+    return (u32)((p[0] >> s) & 1) | ((u32)((p[1] >> s) & 1) << 1) | ((u32)((p[2] >> s) & 1) << 2) | ((u32)((p[3] >> s) & 1) << 3);
+}
+__device__ __forceinline__ u32 kid_index(const Kids& k, u32 v, u32 c) {
+    const size_t e = (size_t)(v >> 6) * 4 + c;
+    return k.cum[e] + (u32)__popcll(k.plane[e] & ((1ull << (v & 63)) - 1));
+}
 
 // Thread-per-node kernels do little per node; a thread takes NPT nodes a grid-width apart (coalescing is kept) and issues
 // all their loads before using any, so a wave has several lines in flight and the grid is NPT times smaller.
@@ -143,13 +167,13 @@ static inline dim3 grid_npt(u64 n) { return dim3((unsigned)((n + 256ull * NPT - 
 
 struct ExpandArgs {
     u32 F;            // frontier width
-    u32 cap;          // record capacity (stride of both record buffers)
+    u32 cap;          // record capacity (stride of both record buffers) = 4 * seg
+    u32 seg;          // handles per symbol segment (>= F rounded up to a tile)
+    u32 nbp;          // tiles of the level = stride of cnt4
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
     u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
-    u32 ns_mask;      // allocation regions - 1 (a block uses region blockIdx & ns_mask)
-    u32 region;       // handles per region
     SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
@@ -159,16 +183,17 @@ template <typename P> struct Vec4;
 template <> struct Vec4<u32> { typedef uint4 type; };
 template <> struct Vec4<u64> { typedef ulonglong4 type; };
 
-// counters (sharded): [0]=reported [1]=lf_steps [2]=rank_ops [3]=block lines fetched
+#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
+
+// The LF-step kernel.  One thread per node of the (colex-ordered) union level; splane receives, per wave, the four bit planes
+// "this sample keeps child c of node j" (the advance kernel derives the children's record handles from them), cnt4 (single
+// sample only: the union trie is the sample's trie) the tile's child counts per symbol for the scan.
 template <typename P>
 __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                                     u32* __restrict__ alloc, u32* __restrict__ tpos, P* __restrict__ valf,
+                                                     u64* __restrict__ splane, u32* __restrict__ cnt4, P* __restrict__ valf,
                                                      u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
-                                                     u32* __restrict__ blockcnt, unsigned long long* __restrict__ childmax) {
+                                                     unsigned long long* __restrict__ childmax) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 shard = blockIdx.x & a.ns_mask;
-    u32 early = 0;
-    if (threadIdx.x == 0) early = atomicAdd(alloc + shard * ALLOC_PITCH, ALLOC_WIN);
     u64 n_lf = 0, n_rank = 0;
     u32 lines = 0;
     u32 r = DEAD;
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     u64 maxchild = 0; // largest frequency among the surviving children (decides the next level's column width)
     u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
     u32 emask = 0;    // which left-extension intervals of this node are non-empty
+    u32 ne = 0;
     RankCache rc;
     rc.bi = ~0ull;
     rc.b1 = ~0ull;
@@ -192,7 +218,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         ++lines;
         if (rc.b1 != rc.bi) { load_blk(ix.blk, rc.b1, rc.r1); ++lines; } else rc.b1 = ~0ull;
         emask = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * a.cap)[r];
-        const u32 ne = __popc(emask);
+        ne = __popc(emask);
         {
             bool matches = false;
 #pragma unroll
@@ -229,71 +255,57 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
             }
         }
     }
-    // ---- compact allocation of the child records: block scan + one atomic per block --------------
-    __shared__ u32 wtot[4];
-    __shared__ u32 sbase, slimit;
-    __shared__ u64 red[4][4];
+    // ---- places of the child records: per symbol, rank of the parent inside its tile (ballots + four wave totals) ----
+    __shared__ u32 wtot[4][4];
+    __shared__ u64 red[4][NCOUNTERS];
     const u32 k = __popc(present);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // exclusive prefix of k (0..4) inside the wave from three ballots (bit-sliced), no LDS traffic
-    u32 excl = 0, wsum = 0;
-    {
-        const u64 lt = (1ull << lane) - 1;
+    const u64 lt = (1ull << lane) - 1;
+    u64 bal[4];
+    u32 excl[4];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const u64 m = __ballot((k >> b) & 1u);
-            excl += (u32)__popcll(m & lt) << b;
-            wsum += (u32)__popcll(m) << b;
-        }
+    for (int c = 0; c < 4; ++c) {
+        bal[c] = __ballot((present >> c) & 1u);
+        excl[c] = (u32)__popcll(bal[c] & lt);
     }
-    if (lane == 0) wtot[w] = wsum;
+    if (lane < 4) {
+        const u64 b = DSM_PICK(bal, lane);
+        wtot[w][lane] = (u32)__popcll(b);
+        splane[((size_t)blockIdx.x * 4 + w) * 4 + lane] = b;
+    }
     {
         u64 m = maxchild;
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) { u64 o = __shfl_xor(m, dd, 64); m = o > m ? o : m; }
         if (lane == 0 && m >= 65535) atomicMax(childmax, (unsigned long long)m);  // only wide values matter (and they are rare)
     }
-    // the four counters travel as one packed word: k <= 4, lines <= 12, lf <= 40, rank-ops <= 160 per lane
-    u64 packed = (u64)k | ((u64)lines << 10) | (n_lf << 22) | (n_rank << 36);
-    packed = wave_sum_u64(packed);
-    if (lane == 0) {
-        red[w][0] = packed & 0x3FF; red[w][3] = (packed >> 10) & 0xFFF; red[w][1] = (packed >> 22) & 0x3FFF; red[w][2] = packed >> 36;
-    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        sbase = shard * a.region + (tot <= ALLOC_WIN ? early : atomicAdd(alloc + shard * ALLOC_PITCH, tot));
-        slimit = (shard + 1) * a.region;
-        if (blockcnt) blockcnt[blockIdx.x] = tot;  // single sample: these are the alive slots of the block's 1024 slots
+    u32 qa[4];  // handle of this lane's child with symbol c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32 off = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) off += q < w ? wtot[q][c] : 0u;
+        qa[c] = (u32)c * a.seg + blockIdx.x * TILE + off + excl[c];
     }
-    if (threadIdx.x < 4) {
-        u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
-    }
-    __syncthreads();
-    u32 pos = sbase + excl;
-    const u32 limit = slimit;  // a region that overflows is detected by the host from its counter
-    for (int q = 0; q < w; ++q) pos += wtot[q];
+    if (cnt4 && threadIdx.x < 4) cnt4[(size_t)threadIdx.x * a.nbp + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
     if (i < a.F) {
-        if (present) {
-            tpos[i] = pos;  // children of one parent get consecutive handles: child c is at tpos + #present children before c
-        }
         // Child records are written child-slot by child-slot (slot j = the j-th surviving base of the lane), not base by base:
-        // most nodes have one child, so a wave usually runs one pass over the ten fields instead of four, and the lanes of a
-        // pass write neighbouring handles.  cj[j] = base of slot j.
-        u32 cj[4];
+        // most nodes have one child, so a wave usually runs one pass over the fields instead of four; the lanes of a pass that
+        // write the same symbol write neighbouring handles.  cj[j] = base of slot j, qj[j] = its handle.
+        u32 cj[4], qj[4];
         {
             u32 m = present;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cj[j] = m ? (u32)__ffs(m) - 1u : 0u; m &= m - 1; }
+            for (int j = 0; j < 4; ++j) { cj[j] = m ? (u32)__ffs(m) - 1u : 0u; m &= m - 1; qj[j] = DSM_PICK(qa, cj[j]); }
         }
         const u32 kmax = (u32)__popcll(__ballot(k > 0)) ? (__any(k > 3) ? 4u : (__any(k > 2) ? 3u : (__any(k > 1) ? 2u : 1u))) : 0u;
-#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
             if (j < kmax && j < k) {
-                const u32 c = cj[j], q = pos + j;
-                if (q < limit) { out[q] = DSM_PICK(Rsp, c); out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1; }
+                const u32 c = cj[j], q = qj[j];
+                out[q] = DSM_PICK(Rsp, c);
+                out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1;
             }
         }
         if (present) {
@@ -335,10 +347,11 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
 #pragma unroll
                     for (u32 j = 0; j < 4; ++j) {
                         if (j < kmax && j < k) {
-                            const u32 c = cj[j], q = pos + j;
+                            const u32 c = cj[j], q = qj[j];
                             const P l = DSM_PICK(lo, c), h = DSM_PICK(hi, c);
                             if (l <= h - 1) {
-                                if (q < limit) { out[(size_t)(2 + cn[j]) * a.cap + q] = l; out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1; }
+                                out[(size_t)(2 + cn[j]) * a.cap + q] = l;
+                                out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1;
                                 ++cn[j];
                                 cm[j] |= 1u << kk;
                             }
@@ -349,13 +362,27 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
             u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * a.cap);
 #pragma unroll
             for (u32 j = 0; j < 4; ++j)
-                if (j < kmax && j < k && pos + j < limit) omask[pos + j] = (u8)cm[j];
+                if (j < kmax && j < k) omask[qj[j]] = (u8)cm[j];
         }
-#undef DSM_PICK
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
         pl[i] = (u8)(present | (mycode << 4));
+    }
+    // counters (exact; the block lines include the ones the ext pass fetched).  They travel as two packed words:
+    // per lane k <= 4, ne <= 4, live <= 1, lines <= 12, lf <= 40, rank-ops <= a few hundred
+    u64 packed = (u64)k | ((u64)ne << 10) | ((u64)(live ? 1u : 0u) << 20) | ((u64)lines << 30);
+    u64 packed2 = n_lf | (n_rank << 24);
+    packed = wave_sum_u64(packed);
+    packed2 = wave_sum_u64(packed2);
+    if (lane == 0) {
+        red[w][0] = packed & 0x3FF; red[w][4] = (packed >> 10) & 0x3FF; red[w][5] = (packed >> 20) & 0x3FF; red[w][3] = packed >> 30;
+        red[w][1] = packed2 & 0xFFFFFF; red[w][2] = packed2 >> 24;
+    }
+    __syncthreads();
+    if (threadIdx.x < NCOUNTERS) {
+        u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
     }
 }
 
@@ -402,73 +429,78 @@ __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// advance: union frontier of the next level.  A thread owns 8 consecutive slots = 2 parents.
+// advance: union frontier of the next level (colex order = stable partition of the children by symbol).
+//   reduce (more than one sample): per parent, how many samples keep each child -> union bit planes, tile counts
+//   scan over the [4][tiles] counts: entry (c, t) = index of the first child with symbol c of tile t
+//   down: node links, reader counts, record handles of the new level, the per-wave directory counts
 // ---------------------------------------------------------------------------------------------
 constexpr int MAX_LOCAL = 273;  // local samples per process (MAX_READERS, metaserver.cpp:19)
-constexpr int ADV_SLOTS = 8;
-constexpr int ADV_TILE = 256 * ADV_SLOTS;
 
-// For two consecutive parents (8 slots): how many samples keep each child (0 = the slot is not a union node).
+// how many samples keep each child of parent u (0 = the slot is not a union node)
 template <typename P>
-__device__ __forceinline__ void slots_eval8(const Xchg& x, u64 u0, u32 nTs[ADV_SLOTS]) {
-#pragma unroll
-    for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] = 0;
-    if (u0 >= x.F) return;
-    const bool two = u0 + 1 < x.F;
+__device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
     const u32 world = x.d / x.nlocal;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nT4[c] = 0;
     for (u32 r = 0; r < world; ++r) {
         const u8* pb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
         for (u32 l = 0; l < x.nlocal; ++l) {
-            const u8* q = pb + (u64)l * x.F + u0;
-            u32 m = (u32)(q[0] & 15) | (two ? (u32)(q[1] & 15) << 4 : 0u);
+            const u32 m = pb[(u64)l * x.F + u];
 #pragma unroll
-            for (int k = 0; k < ADV_SLOTS; ++k) nTs[k] += (m >> k) & 1u;
+            for (int c = 0; c < 4; ++c) nT4[c] += (m >> c) & 1u;
         }
     }
 }
 
-// sinfo[j] = number of samples per slot, written by the reduce pass when d > 1 so that the down-sweep does not re-read d columns
+// sinfo[4u + c] = number of samples that keep child c of parent u, so that the down-sweep does not re-read d columns
 template <typename P>
-__global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u32* __restrict__ sums, u16* __restrict__ sinfo) {
-    const u64 base = (u64)blockIdx.x * ADV_TILE + (u64)threadIdx.x * ADV_SLOTS;
-    u32 nTs[ADV_SLOTS];
-    slots_eval8<P>(x, base >> 2, nTs);
-    u32 s = 0;
-#pragma unroll
-    for (int k = 0; k < ADV_SLOTS; ++k) {
-        s += nTs[k] != 0;
-        if (base + k < x.F * 4) sinfo[base + k] = (u16)nTs[k];
+__global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u16* __restrict__ sinfo, u64* __restrict__ kplane, u32* __restrict__ cnt4, u32 nbp) {
+    __shared__ u32 wtot[4][4];
+    const u32 u = blockIdx.x * TILE + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 nT4[4] = {0, 0, 0, 0};
+    if (u < x.F) {
+        parent_eval<P>(x, u, nT4);
+        uint2 q;
+        q.x = nT4[0] | (nT4[1] << 16);
+        q.y = nT4[2] | (nT4[3] << 16);
+        *reinterpret_cast<uint2*>(sinfo + (size_t)u * 4) = q;
     }
-    u32 tot;
-    block_exclusive_scan<u32>(s, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-// single sample: the expand kernel already counted the alive slots per 256 parents; an advance tile is two of those
-__global__ void pair_sum_kernel(const u32* __restrict__ cnt, u32 ncnt, u32* __restrict__ sums, u32 nb) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    u32 a0 = 2 * b < ncnt ? cnt[2 * b] : 0u, a1 = 2 * b + 1 < ncnt ? cnt[2 * b + 1] : 0u;
-    sums[b] = a0 + a1;
+    u64 bal[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bal[c] = __ballot(nT4[c] != 0);
+    if (lane < 4) {
+        const u64 b = DSM_PICK(bal, lane);
+        wtot[w][lane] = (u32)__popcll(b);
+        kplane[((size_t)blockIdx.x * 4 + w) * 4 + lane] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) cnt4[(size_t)threadIdx.x * nbp + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
 }
 
 struct AdvanceOut {
     u32* slot;        // retained: 4*parent + sym of every new node
-    u32* firstchild;  // retained, per parent (+ sentinel written by the host)
     u16* nT;          // per new node
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
+    const u64* kplane;   // union planes of the parents' level (from the reduce pass, or the sample's own planes when d == 1)
+    u64* kplane_w;       // where the level's retained directory keeps them (null: kplane already is that array)
+    u32* kcum;           // retained directory counts, per wave (written here)
+    const u32* cnt4;     // scanned tile offsets [4][nbp] (unused by a single-tile level)
+    u32 nbp;
+    const u16* sinfo;    // per-slot sample counts from the reduce pass (null: d == 1, or the single tile evaluates the columns itself)
+    u32 eval;            // single tile, more than one sample: evaluate the union from the exchanged columns here
     // per local sample record handles
-    u32* const* rp;          // device tables of nlocal pointers
-    const u32* const* tpos;
+    u32* const* rp;             // device table of nlocal pointers: handles of the new level
+    const u64* const* splane;   // per local sample: the planes its expand kernel wrote (index mode)
+    const u32* const* tpos;     // trie mode: handle of the first allowed child in the parsed stream
     u32 nlocal, rank;
+    u32 seg;           // handles per symbol segment of the record buffers
     u32 cap;           // entries of the new level's arrays: a wider level is reported through the total, not written
-    const u16* sinfo;  // per-slot sample counts from the reduce pass (d > 1, more than one block)
     // what the host needs after the level, gathered by the last block (publish_kernel hands it to the host):
+    const u32* d_total;  // grand total of the scan (more than one tile)
     u32* h_totals;       // [0] = nodes of the new level
-    u32* h_alloc;        // [s * ALLOC_SHARDS + region] = handles taken from that region for local sample s
     u64* h_childmax;     // [r] = largest child frequency reported by rank r
-    u32* alloc;          // the allocation counters of the expand kernels (cleared here for the next level)
 };
 
 // The few words the host reads after a level go to pinned host memory in one tiny launch.  A large kernel that wrote them
@@ -491,106 +523,97 @@ __global__ void publish_kernel(PublishArgs a) {
     if (threadIdx.x == 0 && a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// how many samples keep each child of parent u (0 = the slot is not a union node)
+// Down-sweep, one thread per parent, one tile of 256 parents per block (the tiles of the expand kernel).  A child's index in
+// the new level is a prefix count over its symbol's plane, so the lanes that write children of one symbol write neighbouring
+// entries.
 template <typename P>
-__device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
-    const u32 world = x.d / x.nlocal;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) nT4[c] = 0;
-    for (u32 r = 0; r < world; ++r) {
-        const u8* pb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
-        for (u32 l = 0; l < x.nlocal; ++l) {
-            const u32 m = pb[(u64)l * x.F + u];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) nT4[c] += (m >> c) & 1u;
-        }
-    }
-}
-
-// Down-sweep, one thread per parent (a block covers its tile of ADV_TILE slots as two pieces of 256 parents).  The children
-// of a lane are written child-slot by child-slot: most parents have one child, so the lanes of a pass write neighbouring
-// entries of the new level's arrays.
-constexpr int ADV_PIECES = ADV_TILE / 1024;
-template <typename P>
-__global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __restrict__ offsets, AdvanceOut o, u32* __restrict__ total) {
-    __shared__ u32 wsum[ADV_PIECES][4];
+__global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o) {
+    __shared__ u32 wcnt[4][4];
     const u32 F = (u32)x.F;
-    const u32 u0 = blockIdx.x * (ADV_TILE / 4);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 nT4[ADV_PIECES][4], excl[ADV_PIECES];
+    const u32 u = blockIdx.x * TILE + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t wv = (size_t)blockIdx.x * 4 + w;  // wave index inside the level
+    const u64 lt = (1ull << lane) - 1;
+    u32 nT4[4] = {0, 0, 0, 0};
+    u64 up[4];
+    if (o.eval) {
+        if (u < F) parent_eval<P>(x, u, nT4);
 #pragma unroll
-    for (int pc = 0; pc < ADV_PIECES; ++pc) {
-        const u32 u = u0 + pc * 256 + threadIdx.x;
+        for (int c = 0; c < 4; ++c) up[c] = __ballot(nT4[c] != 0);
+    } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) nT4[pc][c] = 0;
-        if (u < F) {
-            if (o.sinfo) {
+        for (int c = 0; c < 4; ++c) up[c] = o.kplane[wv * 4 + c];
+        if (o.sinfo) {
+            if (u < F) {
                 const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
-                nT4[pc][0] = q.x & 0xFFFFu; nT4[pc][1] = q.x >> 16; nT4[pc][2] = q.y & 0xFFFFu; nT4[pc][3] = q.y >> 16;
-            } else {
-                parent_eval<P>(x, u, nT4[pc]);
+                nT4[0] = q.x & 0xFFFFu; nT4[1] = q.x >> 16; nT4[2] = q.y & 0xFFFFu; nT4[3] = q.y >> 16;
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nT4[c] = (u32)((up[c] >> lane) & 1);
         }
     }
-#pragma unroll
-    for (int pc = 0; pc < ADV_PIECES; ++pc) {
-        const u32 k = (nT4[pc][0] != 0) + (nT4[pc][1] != 0) + (nT4[pc][2] != 0) + (nT4[pc][3] != 0);
-        const u64 lt = (1ull << lane) - 1;
-        u32 e = 0, ws = 0;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const u64 m = __ballot((k >> b) & 1u);
-            e += (u32)__popcll(m & lt) << b;
-            ws += (u32)__popcll(m) << b;
-        }
-        excl[pc] = e;
-        if (lane == 0) wsum[pc][w] = ws;
+    if (lane < 4) {
+        const u64 b = DSM_PICK(up, lane);
+        wcnt[w][lane] = (u32)__popcll(b);
+        if (o.kplane_w) o.kplane_w[wv * 4 + lane] = b;
     }
     __syncthreads();
-    u32 run = offsets ? offsets[blockIdx.x] : 0u;
+    u32 cum[4];  // index of the first child with symbol c of this wave
+    u32 total = 0;
+    {
+        u32 base = 0;
 #pragma unroll
-    for (int pc = 0; pc < ADV_PIECES; ++pc) {
-        const u32 u = u0 + pc * 256 + threadIdx.x;
-        u32 base = run, tot = 0;
+        for (int c = 0; c < 4; ++c) {
+            u32 before = 0, all = 0;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { const u32 t = wsum[pc][kk]; if (kk < w) base += t; tot += t; }
-        run += tot;
-        if (u >= F) continue;
-        const u32 v0 = base + excl[pc];
-        u32 pres = 0, lastT = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if (nT4[pc][c]) { pres |= 1u << c; lastT = nT4[pc][c]; }
-        const u32 nc = __popc(pres);
-        o.firstchild[u] = v0;
-        o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
-        if (!nc || v0 + nc > o.cap) continue;  // a level wider than its arrays is reported through the total, not written
-        u32 mm = pres;
-        for (u32 j = 0; j < nc; ++j) {
-            const u32 c = (u32)__ffs(mm) - 1u;
-            mm &= mm - 1;
-            const u32 t = c == 0 ? nT4[pc][0] : (c == 1 ? nT4[pc][1] : (c == 2 ? nT4[pc][2] : nT4[pc][3]));
-            o.slot[v0 + j] = 4u * u + c;
-            o.nT[v0 + j] = (u16)t;
+            for (u32 q = 0; q < 4; ++q) { const u32 t = wcnt[q][c]; before += q < w ? t : 0u; all += t; }
+            cum[c] = (gridDim.x == 1 ? base : o.cnt4[(size_t)c * o.nbp + blockIdx.x]) + before;
+            base += all;
         }
-        for (u32 sl = 0; sl < o.nlocal; ++sl) {  // record handles of this parent's children in every local sample
-            const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
-            const u32 h = m ? o.tpos[sl][u] : 0u;
+        total = base;
+    }
+    if (lane < 4) o.kcum[wv * 4 + lane] = DSM_PICK(cum, lane);
+    if (u < F) {
+        u32 pres = 0, lastT = 0, vj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vj[c] = cum[c] + (u32)__popcll(up[c] & lt);
+            if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
+        }
+        const u32 nc = __popc(pres);
+        o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (((pres >> c) & 1u) && vj[c] < o.cap) {  // a level wider than its arrays is reported through the total, not written
+                o.slot[vj[c]] = 4u * u + (u32)c;
+                o.nT[vj[c]] = (u16)nT4[c];
+            }
+        }
+        for (u32 sl = 0; sl < o.nlocal && pres; ++sl) {  // record handles of this parent's children in every local sample
             u32* rp = o.rp[sl];
-            u32 m2 = pres;
-            for (u32 j = 0; j < nc; ++j) {
-                const u32 c = (u32)__ffs(m2) - 1u;
-                m2 &= m2 - 1;
-                rp[v0 + j] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+            if (o.tpos) {  // parsed stream: the children of a node are consecutive in the stream's next level
+                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
+                const u32 h = m ? o.tpos[sl][u] : 0u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+            } else {       // index: the place the sample's expand kernel gave the child (see the record layout)
+                const u64* sp = o.splane[sl] + (size_t)blockIdx.x * 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
+                    const u64 mine = sp[w * 4 + c];
+                    u32 off = 0;
+                    for (u32 q = 0; q < w; ++q) off += (u32)__popcll(sp[q * 4 + c]);
+                    rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + blockIdx.x * TILE + off + (u32)__popcll(mine & lt) : DEAD;
+                }
             }
         }
     }
     if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0) {
-            if (total) *total = run;
-            o.firstchild[F] = run;  // sentinel: the filter of this level runs before the host has seen the total
-            o.h_totals[0] = run;
-        }
-        for (u32 q = threadIdx.x; q < o.nlocal * ALLOC_SHARDS; q += blockDim.x) { o.h_alloc[q] = o.alloc[q * ALLOC_PITCH]; o.alloc[q * ALLOC_PITCH] = 0; }
+        if (threadIdx.x == 0) o.h_totals[0] = gridDim.x == 1 ? total : *o.d_total;
         const u32 world = x.d / x.nlocal;
         for (u32 r = threadIdx.x; r < world; r += blockDim.x)
             o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr);
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, const u32* __
 // round (metaserver.cpp:159-189, 322-339).  Orders are nibble-packed, first iterated id in bits 0-3.
 // ---------------------------------------------------------------------------------------------
 template <typename P>
-__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, const u32* __restrict__ firstchild,
+__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, Kids kids,
                              u64* __restrict__ order_next) {
     u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= F) return;
@@ -628,13 +651,12 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
             ++icnt[f];
         }
     }
-    u32 v = firstchild[u];
     for (int i = 0; i < 4; ++i) {
         if (!icnt[i]) continue;
         // iteration order of children[i] = reverse insertion order
         u64 rev = 0;
         for (u32 k = 0; k < icnt[i]; ++k) rev |= ((ins[i] >> (4 * k)) & 15) << (4 * (icnt[i] - 1 - k));
-        order_next[v++] = rev;
+        order_next[kid_index(kids, u, (u32)i)] = rev;
         // next round: the readers of this child (in its iteration order) read their next child
         for (u32 k = 0; k < icnt[i]; ++k) {
             u32 r = (u32)((rev >> (4 * k)) & 15);
@@ -651,7 +673,7 @@ __global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u6
 // More than 13 samples: the sets rehash (13 -> 29 -> 59 -> ...) and ids share buckets, so the order is replayed with the
 // container model of setorder.h.  Orders are u16 arrays, d entries per node.
 template <typename P, int MAXD>
-__global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u16* __restrict__ order, const u32* __restrict__ firstchild,
+__global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u16* __restrict__ order, Kids kids,
                                  u16* __restrict__ order_next) {
     // per-thread working set in scratch: byte-sized ids when they fit (at most 64 samples: 575 B instead of 1.1 KB)
     typedef typename std::conditional<(MAXD <= 250), u8, u16>::type K;
@@ -670,13 +692,11 @@ __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, cons
         mask[r] = (u8)m;
         if (m) { int f = __ffs(m) - 1; ins[f][icnt[f]++] = (K)r; }
     }
-    u32 v = firstchild[u];
     for (int i = 0; i < 4; ++i) {
         if (!icnt[i]) continue;
         set_iteration_order<K>(ins[i], icnt[i], loc, work, (u32)MAXD);
-        u16* dst = order_next + (size_t)v * x.d;
+        u16* dst = order_next + (size_t)kid_index(kids, u, (u32)i) * x.d;
         for (u32 k = 0; k < icnt[i]; ++k) dst[k] = (u16)loc[k];
-        ++v;
         for (u32 k = 0; k < icnt[i]; ++k) {  // next round: this child's readers, in its iteration order
             const u32 r = loc[k];
             u32 m = mask[r] & ~((2u << i) - 1);
@@ -701,7 +721,7 @@ struct FilterArgs {
 constexpr double ENT_MARGIN = 1e-4;
 // key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
 template <typename P>
-__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, const u32* __restrict__ firstchild,
+__global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, Kids kids,
                                                      const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
     const u32 stride = gridDim.x * blockDim.x;
     const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -711,7 +731,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const
     for (int i = 0; i < NPT; ++i) {  // the cheap predicates of all NPT nodes first: their loads are in flight together
         const u32 v = v0 + i * stride, vc = v < a.F ? v : 0u;
         t[i] = nT[vc];
-        const u32 nc = firstchild[vc + 1] - firstchild[vc];
+        const u32 nc = __popc(kid_mask(kids, vc));
         const u32 same = samechild[vc];
         bool o = v < a.F;
         if (a.depth < a.mindepth) o = false;
@@ -802,56 +822,53 @@ __global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict_
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
-// bottom-up: agg[v] = own[v] + sum over children agg_child          (children of v: [fc[v], fc[v+1]) )
+// bottom-up: agg[v] = own[v] + sum over children agg_child          (children of v: kid_index(kids, v, c) for c in kid_mask)
 template <typename T, typename OwnT>
-__global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__ own, const u32* __restrict__ firstchild, const T* __restrict__ child_agg,
+__global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__ own, Kids kids, const T* __restrict__ child_agg,
                                                  T* __restrict__ agg) {
     const u32 stride = gridDim.x * blockDim.x;
     const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 fc[NPT], nc[NPT];
+    u32 m[NPT];
     T s[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
-        fc[i] = firstchild[vc];
-        nc[i] = v < F ? firstchild[vc + 1] - fc[i] : 0u;
+        m[i] = v < F && child_agg ? kid_mask(kids, vc) : 0u;
         s[i] = own ? (T)own[vc] : (T)1;
     }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        if (nc[i]) s[i] += child_agg[fc[i]];   // nearly every node has one child: fetch it with the batch
-    }
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        for (u32 k = 1; k < nc[i]; ++k) s[i] += child_agg[fc[i] + k];
         const u32 v = v0 + i * stride;
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c)
+            if ((m[i] >> c) & 1u) s[i] += child_agg[kid_index(kids, v, c)];
         if (v < F) agg[v] = s[i];
     }
 }
-// top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]
+// top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]   (children in A,C,G,T order)
 template <typename T>
-__global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ start, T lead, const u32* __restrict__ firstchild,
+__global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ start, T lead, Kids kids,
                                                    const T* __restrict__ child_agg, T* __restrict__ child_start) {
     const u32 stride = gridDim.x * blockDim.x;
     const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 fc[NPT], nc[NPT];
+    u32 m[NPT];
     T s[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
-        fc[i] = firstchild[vc];
-        nc[i] = v < F ? firstchild[vc + 1] - fc[i] : 0u;
+        m[i] = v < F ? kid_mask(kids, vc) : 0u;
         s[i] = start[vc] + lead;
     }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        if (nc[i]) child_start[fc[i]] = s[i];
-    }
+        const u32 v = v0 + i * stride;
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        for (u32 k = 1; k < nc[i]; ++k) {
-            s[i] += child_agg[fc[i] + k - 1];
-            child_start[fc[i] + k] = s[i];
+        for (u32 c = 0; c < 4; ++c) {
+            if ((m[i] >> c) & 1u) {
+                const u32 ch = kid_index(kids, v, c);
+                child_start[ch] = s[i];
+                if (m[i] >> (c + 1)) s[i] += child_agg[ch];  // only when a later sibling exists
+            }
         }
     }
 }
@@ -975,7 +992,9 @@ struct Arena {
 struct LevelHost {
     u32 n = 0;
     u32* slot = nullptr;        // 4 * parent + sym
-    u32* firstchild = nullptr;  // n + 1 entries
+    u64* kplane = nullptr;      // children directory (struct Kids): 4 planes and 4 counts per 64 nodes, whole tiles
+    u32* kcum = nullptr;
+    Kids kids() const { Kids k; k.plane = kplane; k.cum = kcum; return k; }
     // mine
     u8* cand_flag = nullptr;
     u32 ncand = 0, npairs = 0;
@@ -1375,19 +1394,20 @@ class Engine {
     u32 Fcap = 0;
     bool multi = false;       // the level exchange goes through the host's all-gather (world > 1, or forced for rehearsals)
     u32 pub_seq = 0;          // sequence number of the last publish kernel
-    u32 Rcap = 0;             // handles of a record buffer (Fcap plus the slack of the windowed allocation)
-    u32 ns_shards = 1, region = 0;
-    u32* h_alloc = nullptr;   // pinned [nlocal][ALLOC_SHARDS]
-    u32* d_pub_tot = nullptr; u32* d_pub_alloc = nullptr; u64* d_pub_cmax = nullptr;  // device side of what publish_kernel hands over
-    std::vector<P*> rec[2];     // compact child records, ping-pong by level
+    u32 Seg = 0;              // handles per symbol segment of a record buffer: Fcap rounded up to whole tiles
+    u32 Rcap = 0;             // handles of a record buffer = 4 * Seg
+    u32* d_pub_tot = nullptr; u64* d_pub_cmax = nullptr;  // device side of what publish_kernel hands over
+    std::vector<P*> rec[2];     // child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
-    std::vector<u32*> tpos;     // handle of the first child record of every node of the level being expanded
-    u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*] and tpos[*] for the advance kernel
+    std::vector<u32*> tpos;     // trie mode: handle of the first child of every node of the level being expanded
+    std::vector<u64*> splane;   // index mode: per wave of the level being expanded, which children the sample keeps
+    u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*], tpos[*] and splane[*] for the advance kernel
     u32** d_tpos_tab = nullptr;
+    u64** d_splane_tab = nullptr;
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
-    u32 *adv_sums = nullptr, *scan_tmp = nullptr, *blockcnt = nullptr;
+    u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced, scanned in place
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8* samechild = nullptr;
@@ -1395,7 +1415,6 @@ class Engine {
     u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_key = nullptr, *cand_keyscan = nullptr, *scan_tmp64 = nullptr;
     u64* d_counters = nullptr;
-    u32* d_alloc = nullptr;   // [nlocal] compact-record allocation counters
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, [8..8+MAX_LOCAL) record allocations, [300..] u64 totals
@@ -1407,14 +1426,12 @@ class Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evpool;
     dsm_stats stats;
-    u64 lines_fetched = 0;
     u32 splits = 0;
     Emitter emitter;
 
     ~Engine() {
         for (void* p : owned) (void)hipFree(p);
         if (h_totals) (void)hipHostFree(h_totals);
-        if (h_alloc) (void)hipHostFree(h_alloc);
         if (h_childmax) (void)hipHostFree(h_childmax);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1493,13 +1510,13 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) * 9 / 4 + 2 * 4 + 4)   // rec x2 (with the window slack), rp x2, tpos
+        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) * 4 + 2 * 4 + 4 + 1)   // rec x2 (four symbol segments each), rp x2, tpos, planes
                    + (u64)nlocal * (sizeof(P) + 1)                             // send
                    + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
         u64 fc = budget / 3 / perF;
-        if (fc > (1u << 28)) fc = 1u << 28;
-        if (fc < 1024) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
+        if (fc > (1u << 28) - TILE) fc = (1u << 28) - TILE;
+        if (fc < 512) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         if (fc > fbound) fc = fbound < 1024 ? 1024 : fbound;
         Fcap = (u32)fc;
         bpr_cap = (((u64)nlocal * Fcap * (sizeof(P) + 1) + 15) & ~15ull) + 16;
@@ -1524,25 +1541,25 @@ class Engine {
             if (int rc = agree_min(mine, &agreed)) return rc;
             Fcap = (u32)agreed;
         }
-        // Record handles: a level reserves at most ALLOC_WIN per 256 parents plus, for blocks that outgrow their window, their
-        // exact child count -- never more than 1.25 * parents + children + one window.
-        {
-            const u64 rc64 = (u64)Fcap * 9 / 4 + 4096;
-            Rcap = rc64 > 0xFFFFFF00ull ? 0xFFFFFF00u : (u32)rc64;
-            ns_shards = 1;
-            while (ns_shards < ALLOC_SHARDS && Rcap / (ns_shards * 2) >= 65536) ns_shards *= 2;
-            region = Rcap / ns_shards;
-        }
+        // Record handles: four symbol segments of Seg handles, a tile of 256 parents owns 256 handles in each (see the record layout)
+        Seg = (Fcap + TILE - 1) / TILE * TILE;
+        Rcap = 4 * Seg;
+        const size_t ntile = Seg / TILE, nwave = ntile * 4;
         const u64 slots = (u64)Fcap * 4;
         for (int s = 0; s < nlocal; ++s) {
-            P *a, *b;
-            u32 *r0, *r1, *tp;
-            if (int rc = dalloc(a, rec_elems<P>(Rcap))) return rc;
-            if (int rc = dalloc(b, rec_elems<P>(Rcap))) return rc;
+            P *a = nullptr, *b = nullptr;
+            u32 *r0, *r1, *tp = nullptr;
+            u64* pln = nullptr;
+            if (!trie_mode) {
+                if (int rc = dalloc(a, rec_elems<P>(Rcap))) return rc;
+                if (int rc = dalloc(b, rec_elems<P>(Rcap))) return rc;
+                if (int rc = dalloc(pln, nwave * 4)) return rc;
+            } else {
+                if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
+            }
             if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
             if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
-            if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
-            rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp);
+            rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp); splane.push_back(pln);
         }
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(d_rp_tab[k], (size_t)nlocal)) return rc;
@@ -1550,11 +1567,11 @@ class Engine {
         }
         if (int rc = dalloc(d_tpos_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_tpos_tab, tpos.data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
-        const size_t nadv = (size_t)((slots + ADV_TILE - 1) / ADV_TILE) + 8;
-        if (int rc = dalloc(adv_sums, nadv)) return rc;
-        if (int rc = dalloc(blockcnt, (size_t)Fcap / 256 + 8)) return rc;
+        if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
+        DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
+        if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
-        if (int rc = dalloc(scan_tmp, scan_tmp_elems(nadv) + 8)) return rc;
+        if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
             if (int rc = dalloc(order[k], Fcap)) return rc;
@@ -1567,13 +1584,9 @@ class Engine {
         if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
-        if (int rc = dalloc(d_alloc, (size_t)nlocal * ALLOC_SHARDS * ALLOC_PITCH)) return rc;
-        DSM_HIP(hipHostMalloc((void**)&h_alloc, (size_t)nlocal * ALLOC_SHARDS * sizeof(u32)));
-        memset(h_alloc, 0, (size_t)nlocal * ALLOC_SHARDS * sizeof(u32));
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
         if (int rc = dalloc(d_pub_tot, 8)) return rc;
-        if (int rc = dalloc(d_pub_alloc, (size_t)nlocal * ALLOC_SHARDS)) return rc;
         if (int rc = dalloc(d_pub_cmax, (size_t)(world > 0 ? world : 1))) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 320 * sizeof(u32)));
         DSM_HIP(hipHostMalloc((void**)&h_childmax, (size_t)(world > 0 ? world : 1) * sizeof(u64)));
@@ -1629,6 +1642,14 @@ class Engine {
         return x;
     }
 
+    // children directory of a level: whole tiles, written by the advance down-sweep of that level
+    int alloc_kids(LevelHost& lv) {
+        const size_t nw = ((size_t)lv.n + TILE - 1) / TILE * 4;
+        ARENA_GET(lv.kplane, u64, 4 * nw);
+        ARENA_GET(lv.kcum, u32, 4 * nw);
+        return 0;
+    }
+
     hipEvent_t pool_event(size_t k) {
         while (evpool.size() <= k) {
             hipEvent_t e = nullptr;
@@ -1664,7 +1685,6 @@ class Engine {
         std::vector<LevelHost> L;
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
-        DSM_HIP(hipMemsetAsync(d_alloc, 0, (size_t)nlocal * ALLOC_SHARDS * ALLOC_PITCH * sizeof(u32), st));  // from here on the advance down-sweep clears them
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -1699,7 +1719,7 @@ class Engine {
             LevelHost root;
             root.n = 1;
             ARENA_GET(root.slot, u32, 1);
-            ARENA_GET(root.firstchild, u32, 2);
+            if (int rc = alloc_kids(root)) return rc;
             L.push_back(root);
             u16 rootT = (u16)d;
             DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
@@ -1740,8 +1760,7 @@ class Engine {
             u8* send = multi ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
-            ea.F = F; ea.cap = Rcap; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
-            ea.ns_mask = ns_shards - 1; ea.region = region;
+            ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
             unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send);  // header, cleared by the previous level's publish kernel
             if (depth < prefix.size()) {
                 const char* q = strchr(bases, prefix[depth]);
@@ -1777,9 +1796,11 @@ class Engine {
                 for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
                 P* cf = reinterpret_cast<P*>(send + XHDR + (size_t)s * F * fb);           // this sample's frequency column
                 u8* cl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;           // children nibble | left char << 4
-                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], d_alloc + (size_t)s * ALLOC_SHARDS * ALLOC_PITCH,
-                                   tpos[s], cf, cl, ea, d_counters, (d == 1 && !trie_mode) ? blockcnt : (u32*)nullptr, d_childmax);
+                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s],
+                                   (d == 1 && ea.nbp > 1) ? cnt4 : (u32*)nullptr, cf, cl, ea, d_counters, d_childmax);
                 ++stats.expand_launches;
+                stats.expand_slots += F;
+                stats.expand_column_bytes += (u64)F * (fb + 1);
             }
             DSM_HIP(hipEventRecord(ea1, st));
             if (device < 16) { g_expand_chain.last[device] = ea1; g_expand_chain.owner[device] = this; }
@@ -1824,26 +1845,29 @@ class Engine {
             const size_t mark2 = arena.off;
             u32* new_slot2 = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
             if (!new_slot2) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
-            const u32 nb = (u32)((slots + ADV_TILE - 1) / ADV_TILE);
+            const u32 nbp = (F + TILE - 1) / TILE;  // tiles of this level
             AdvanceOut ao;
             memset(&ao, 0, sizeof ao);
-            ao.slot = new_slot2; ao.firstchild = me.firstchild; ao.nT = nT[nxt]; ao.samechild = samechild;
+            ao.slot = new_slot2; ao.nT = nT[nxt]; ao.samechild = samechild;
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
-            ao.h_totals = d_pub_tot; ao.h_alloc = d_pub_alloc; ao.h_childmax = d_pub_cmax; ao.alloc = d_alloc;
+            ao.seg = Seg;
+            ao.h_totals = d_pub_tot; ao.h_childmax = d_pub_cmax; ao.d_total = d_totals;
             ao.rp = d_rp_tab[nxt];
-            ao.tpos = d_tpos_tab;
-            if (nb == 1) {
-                hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, (const u32*)nullptr, ao, d_totals);
-            } else {
-                ao.sinfo = (d > 1 || trie_mode) ? sinfo : nullptr;
-                if (d == 1 && !trie_mode)
-                    hipLaunchKernelGGL(pair_sum_kernel, grid_for(nb), dim3(256), 0, st, blockcnt, (u32)((F + 255) / 256), adv_sums, nb);
-                else
-                    hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nb), dim3(256), 0, st, x, adv_sums, sinfo);
-                exclusive_scan<u32, u32>(adv_sums, adv_sums, nb, scan_tmp, d_totals, st);
-                hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nb), dim3(256), 0, st, x, (const u32*)adv_sums, ao, (u32*)nullptr);
+            ao.tpos = trie_mode ? d_tpos_tab : nullptr;
+            ao.splane = d_splane_tab;
+            ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp;
+            const bool merged = d > 1 || trie_mode;  // the union of several columns (a parsed stream is treated alike)
+            if (merged && nbp == 1) {  // a single tile evaluates the columns itself
+                ao.eval = 1; ao.kplane_w = me.kplane;
+            } else if (merged) {
+                hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nbp), dim3(256), 0, st, x, sinfo, me.kplane, cnt4, nbp);
+                ao.kplane = me.kplane; ao.sinfo = sinfo;
+            } else {                   // one sample: the union trie is its trie, the expand kernel wrote planes and tile counts
+                ao.kplane = splane[0]; ao.kplane_w = me.kplane;
             }
+            if (nbp > 1) exclusive_scan<u32, u32>(cnt4, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
+            hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
@@ -1852,7 +1876,6 @@ class Engine {
                 PublishArgs pa;
                 memset(&pa, 0, sizeof pa);
                 pa.src[0] = d_pub_tot; pa.dst[0] = h_totals; pa.words[0] = 1;
-                pa.src[1] = d_pub_alloc; pa.dst[1] = h_alloc; pa.words[1] = trie_mode ? 0u : (u32)nlocal * ALLOC_SHARDS;
                 pa.src[2] = reinterpret_cast<const u32*>(d_pub_cmax); pa.dst[2] = reinterpret_cast<u32*>(h_childmax); pa.words[2] = 2u * (u32)world;
                 if (filtered) {
                     pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
@@ -1881,24 +1904,22 @@ class Engine {
                 for (int r = 0; r < world; ++r) mx = h_childmax[r] > mx ? h_childmax[r] : mx;
                 w16 = mx < 65535 && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
             }
-            for (size_t q = 0; q < (size_t)nlocal * ALLOC_SHARDS && !trie_mode; ++q)
-                if (h_alloc[q] > region) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             // commit the provisional window at its real size
             arena.off = mark2;
             child.n = Fn;
             if (Fn) {
                 child.slot = arena.get<u32>(Fn);  // same address as new_slot2
-                ARENA_GET(child.firstchild, u32, (size_t)Fn + 1);
+                if (int rc = alloc_kids(child)) return rc;
                 if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16)) return rc;  // w16 already describes the next level
                 // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
                 if (!(emit || capture)) {}
                 else if (order_mode == 1)
-                    hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.firstchild, order[nxt]);
+                    hipLaunchKernelGGL((order_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, nT[cur], order[cur], me.kids(), order[nxt]);
                 else if (order_mode == 2 && d <= 64)
-                    hipLaunchKernelGGL((order_big_kernel<P, 64>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
+                    hipLaunchKernelGGL((order_big_kernel<P, 64>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.kids(), order16[nxt]);
                 else if (order_mode == 2)
-                    hipLaunchKernelGGL((order_big_kernel<P, 273>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.firstchild, order16[nxt]);
+                    hipLaunchKernelGGL((order_big_kernel<P, 273>), grid_for(F, 64), dim3(64), 0, st, F, x, nT[cur], order16[cur], me.kids(), order16[nxt]);
             }
             if (Fn && order_mode && seed && depth + 1 == seed->depth) {  // the sub-prefix root keeps its order from the unsplit trie
                 const std::vector<u16>& so = seed->ord[0];
@@ -1979,17 +2000,19 @@ class Engine {
             expand_ms += t;
         }
         stats.expand_ms += expand_ms;
-        u64 hc[4] = {0, 0, 0, 0};
+        u64 hc[NCOUNTERS] = {0, 0, 0, 0, 0, 0};
         {
             std::vector<u64> sh((size_t)COUNTER_SHARDS * 8);
             DSM_HIP(hipMemcpy(sh.data(), d_counters, sh.size() * sizeof(u64), hipMemcpyDeviceToHost));
             for (int k = 0; k < COUNTER_SHARDS; ++k)
-                for (int c = 0; c < 4; ++c) hc[c] += sh[(size_t)k * 8 + c];
+                for (int c = 0; c < NCOUNTERS; ++c) hc[c] += sh[(size_t)k * 8 + c];
         }
         stats.reported += hc[0];
         stats.lf_steps += hc[1];
         stats.rank_ops += hc[2];
-        lines_fetched += hc[3];
+        stats.index_lines += hc[3];
+        stats.ext_read += hc[4];
+        stats.records_read += hc[5];
         return 0;
     }
 
@@ -2009,7 +2032,7 @@ class Engine {
     int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
         const FilterArgs fa = filter_args(F, depth, order_mode);
         const bool one = d == 1;
-        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.firstchild, samechild,
+        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild,
                            me.cand_flag, one ? (u64*)nullptr : cand_key);
         u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         if (one) {
@@ -2058,7 +2081,7 @@ class Engine {
                 EARENA_GET(L[l].cand_flag, u8, L[l].n);
                 DSM_HIP(hipMemsetAsync(L[l].cand_flag, 0, L[l].n, st));
             }
-            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].firstchild, child_sub, L[l].sub);
+            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].kids(), child_sub, L[l].sub);
         }
         // top-down: start offsets, two rolling arrays
         u32 *t_level, *t_cidx;
@@ -2073,7 +2096,7 @@ class Engine {
         for (u32 l = 0; l + 1 < nlev; ++l) {
             u32* s_cur = startbuf[l & 1];
             u32* s_next = startbuf[(l + 1) & 1];
-            hipLaunchKernelGGL((down_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].firstchild, L[l + 1].sub, s_next);
+            hipLaunchKernelGGL((down_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].kids(), L[l + 1].sub, s_next);
             if (L[l + 1].ncand)
                 hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, s_next, L[l + 1].sub, l + 1,
                                    t_level, t_cidx);
@@ -2185,25 +2208,25 @@ class Engine {
             ARENA_GET(L[l].off, u64, L[l].n);
         }
         for (u32 l = nlev; l-- > 0;)  // subtree node counts
-            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].firstchild,
+            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].kids(),
                                l + 1 < nlev ? L[l + 1].sz : nullptr, L[l].sz);
         {  // pre-order numbers: pre(child_k) = pre(v) + 1 + sum sz(earlier siblings); root pre = -1
             u64 m1 = ~0ull;
             DSM_HIP(hipMemcpyAsync(L[0].pre, &m1, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].firstchild, L[l + 1].sz, L[l + 1].pre);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].kids(), L[l + 1].sz, L[l + 1].pre);
         }
         for (u32 l = 1; l < nlev; ++l)
             hipLaunchKernelGGL((stream_own_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, (const P*)L[l].freq, L[l].pre, L[l].sz, L[l].own);
         DSM_HIP(hipMemsetAsync(L[0].own, 0, 8, st));
         for (u32 l = nlev; l-- > 0;)  // subtree bytes
-            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].firstchild,
+            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].kids(),
                                l + 1 < nlev ? L[l + 1].bytes : nullptr, L[l].bytes);
         {  // byte offsets: off(child_k) = off(v) + 2 + sum bytes(earlier siblings); root off = -2
             u64 m2 = ~0ull - 1;
             DSM_HIP(hipMemcpyAsync(L[0].off, &m2, 8, hipMemcpyHostToDevice, st));
             for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].firstchild, L[l + 1].bytes, L[l + 1].off);
+                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].kids(), L[l + 1].bytes, L[l + 1].off);
         }
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));

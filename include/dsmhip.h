@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 1
+#define DSM_ABI_VERSION 2
 
 /* error codes (negative errno values) */
 #define DSM_OK 0
@@ -112,6 +112,12 @@ typedef struct dsm_stats {
     double host_ms;          /* host post-processing (exact entropy, tuple assembly) */
     uint64_t pair_order_exact; /* 1 when id:freq order and FP summation order follow the reference bit for bit */
     uint64_t splits;         /* prefixes that were split into longer ones because a level did not fit the device buffers */
+    /* exact memory work of the LF-step (expand) kernel, counted by the kernel itself (ABI version 2) */
+    uint64_t index_lines;    /* 64-byte index blocks it fetched */
+    uint64_t records_read;   /* frontier records it read (nodes present in the sample) */
+    uint64_t ext_read;       /* left-extension intervals it read = intervals the previous level wrote */
+    uint64_t expand_slots;   /* threads it ran = frontier nodes x local samples (absent nodes only cost their handle and column entry) */
+    uint64_t expand_column_bytes; /* bytes of exchange column it wrote */
 } dsm_stats;
 
 /* ------------------------------------------------------------------------------------------------

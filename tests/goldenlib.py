@@ -59,3 +59,24 @@ class Golden:
 
     def server_out(self, setname, cfg, prefix):
         return self.read("%s/server.%s.%s.txt.gz" % (setname, cfg, prefix))
+
+
+def wait_listen(port, proc=None, timeout=30.0):
+    """Block until some process listens on TCP `port` (from /proc/net/tcp: no probe connection that a server would take
+    for a client).  Returns False when `proc` exits first or the time is up."""
+    import time
+    want = "%04X" % port
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        for f in ("/proc/net/tcp", "/proc/net/tcp6"):
+            try:
+                for line in open(f).read().splitlines()[1:]:
+                    col = line.split()
+                    if col[1].rsplit(":", 1)[1] == want and col[3] == "0A":
+                        return True
+            except OSError:
+                pass
+        if proc is not None and proc.poll() is not None:
+            return False
+        time.sleep(0.02)
+    return False

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), "libdsmhip.so does not export " + s
-    assert L.dsm_abi_version() == 1
+    assert L.dsm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert (p.fmin, p.pmin, p.pmax, p.maxdepth, p.world_size) == (10, 2, 0, 0xFFFFFFFF, 1)
     assert p.emax == -1.0 and p.emin == 0.0
     assert C.sizeof(pydsm.Code) == 16
-    assert C.sizeof(pydsm.Stats) == 15 * 8
+    assert C.sizeof(pydsm.Stats) == 20 * 8
 
 
 def test_no_cpu_fallback_without_gpu(golden):

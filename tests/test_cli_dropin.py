@@ -7,6 +7,8 @@ import time
 
 import pytest
 
+from goldenlib import wait_listen
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "dsm-framework_amd", "host")
@@ -52,7 +54,9 @@ def test_our_client_feeds_the_unmodified_reference_server(golden, tmp_path):
         pr.stdin.close()
         procs.append((p, pr, out))
         hosts += "127.0.0.1 %d %s\n" % (port, p)
-    time.sleep(0.5)
+    ports = [int(l.split()[1]) for l in hosts.splitlines()]
+    for (_, pr, _), pt in zip(procs, ports):
+        assert wait_listen(pt, pr), "metaserver did not start listening"
     clients = []
     for n in names:
         c = subprocess.Popen([os.path.join(HOST, "metaenumerate_hip"), "--fmin", "2", golden.fmi("toy3", n)], stdin=subprocess.PIPE,

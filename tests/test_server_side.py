@@ -8,7 +8,7 @@ import time
 
 import pytest
 
-from goldenlib import server_args_to_kw
+from goldenlib import server_args_to_kw, wait_listen
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -103,7 +103,7 @@ def test_reference_clients_feed_our_server(golden, tmp_path):
                                stderr=subprocess.PIPE)
         srv.stdin.write(("\n".join(names) + "\n").encode())
         srv.stdin.close()
-        time.sleep(0.5)
+        assert wait_listen(port, srv), "metaserver_hip did not start listening"
         clients = []
         for n in names:
             c = subprocess.Popen([os.path.join(REF, "metaenumerate"), "--fmin", "2", golden.fmi("toy3", n)], stdin=subprocess.PIPE,
