@@ -200,7 +200,7 @@ def main():
             ln["ex"].gate = gate
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
-           "device_ms": 0.0, "host_ms": 0.0, "cand": 0}
+           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "ext_read": 0, "slots": 0, "colbytes": 0}
     import threading
     tot_lock = threading.Lock()
 
@@ -230,6 +230,11 @@ def main():
                     tot["device_ms"] += st.device_ms
                     tot["host_ms"] += st.host_ms
                     tot["cand"] += st.candidates
+                    tot["index_lines"] += st.index_lines
+                    tot["records_read"] += st.records_read
+                    tot["ext_read"] += st.ext_read
+                    tot["slots"] += st.expand_slots
+                    tot["colbytes"] += st.expand_column_bytes
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             if world > 1:  # the other ranks are blocked in a collective: fail the whole job instead of hanging it
@@ -297,7 +302,15 @@ def main():
         ln["miner"].close()
 
     if rank == 0:
-        ach = tot["rank_ops"] * ALG_BYTES_PER_RANK / (tot["expand_ms"] * 1e-3) / 1e9 if tot["expand_ms"] > 0 else 0.0
+        # Bytes the LF-step kernel moves, from its own exact counters: 64 B per index block a wave asks
+        # for, per thread a 4-byte record handle, its column entry and 0.5 B of child planes, per record read or written
+        # sp, ep and the mask byte, per left-extension interval read or written its two ends.
+        pbytes = 8 if (args.wide or ix.n >= 0xFFFFFFF0) else 4
+        kernel_bytes = (64 * tot["index_lines"] + 4 * tot["slots"] + tot["slots"] // 2 + tot["colbytes"]
+                        + (tot["records_read"] + tot["reported"]) * (2 * pbytes + 1) + 2 * tot["ext_read"] * 2 * pbytes)
+        esec = tot["expand_ms"] * 1e-3
+        ach = kernel_bytes / esec / 1e9 if esec > 0 else 0.0
+        ref_equiv = tot["rank_ops"] * ALG_BYTES_PER_RANK / esec / 1e9 if esec > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 --pmc (see profiles/README)
         if os.path.exists(tj):
@@ -318,12 +331,19 @@ def main():
                                                                               ", wire-stream mode" if args.stream_mode else "", len(prefixes)),
                        "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         # the same kernel priced by its measured HBM traffic (profiles/traffic.json) instead of the reference's rank-ops
+                         # `achieved` = bytes the kernel itself counted / HIP-event time of its launches (live, this run).
+                         # `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes of the same command (offline profile,
+                         # profiles/traffic.json; null when this run's configuration differs from the profiled one)
+                         "traffic": traffic, "traffic_source": "profiles/traffic.json (offline rocprofv3 --pmc of the same command)" if traffic else None,
                          "traffic_gbs": (traffic / (tot["expand_ms"] / max(1, tot["launches"]) * 1e-3) / 1e9) if traffic and tot["expand_ms"] > 0 else None,
                          "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),
-                         "alg_bytes_per_launch": tot["rank_ops"] * ALG_BYTES_PER_RANK / max(1, tot["launches"]),
+                         "bytes_per_launch": kernel_bytes / max(1, tot["launches"]),
+                         "bytes_per_node": kernel_bytes / max(1, tot["reported"]),
+                         "index_lines_per_node": tot["index_lines"] / max(1, tot["reported"]),
+                         # SURVEY 8d's accounting (17 B per BitRank::rank the REFERENCE would execute): measures the data-structure
+                         # win, not kernel efficiency -- one 64-byte block answers many reference rank-ops, so it may exceed the peak
+                         "reference_equivalent_gbs": ref_equiv,
                          # with more than one lane the expand launches of the lanes share the device: their durations
                          # (and so `achieved`) describe two kernels running side by side, not one kernel alone
                          "concurrent_lanes": nlanes},

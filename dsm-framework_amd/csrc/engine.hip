@@ -41,15 +41,14 @@ namespace dsm {
 // ---------------------------------------------------------------------------------------------
 struct RankCache {
     u64 bi;   // block currently held in r
-    u64 b1;   // block preloaded in r1 (the block of ep+1), ~0 when none
-    Blk16 r, r1;
+    Blk16 r;
 };
 
 __device__ __forceinline__ void rc_select(const DevIndex& ix, RankCache& rc, u64 x, u32& lines) {
     u64 bi = x >> BLK_SHIFT;
     if (bi != rc.bi) {
-        if (bi == rc.b1) rc.r = rc.r1;
-        else { load_blk(ix.blk, bi, rc.r); ++lines; }
+        load_blk(ix.blk, bi, rc.r);
+        ++lines;
         rc.bi = bi;
     }
 }
@@ -69,18 +68,19 @@ __device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4])
 }
 
 // Superblock bases (C[c] + occurrences of c before the superblock).  An index below 2^31 symbols has one superblock:
-// its four bases travel as kernel arguments (scalar registers) instead of a dependent vector load per rank.
+// its four bases travel as kernel arguments (scalar registers) instead of a dependent vector load per rank.  The choice is
+// a template parameter (ONESB), not a run-time select: selecting between the argument block and the device array turns
+// every access into a flat load, whose wait also drains every prefetch in flight.
 struct SbArgs {
     u64 sb0[4];
-    u32 one_sb;
 };
 
 // LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
-template <typename P>
+template <typename P, bool ONESB>
 __device__ __forceinline__ void rank4_blk(const DevIndex& ix, const SbArgs& sa, const Blk16& r, u64 x, P out[4]) {
     u32 c4[4];
     blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
-    if (sa.one_sb) {
+    if (ONESB) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = (P)(sa.sb0[c] + r.cnt[c] + c4[c]);
     } else {
@@ -91,7 +91,7 @@ __device__ __forceinline__ void rank4_blk(const DevIndex& ix, const SbArgs& sa, 
 }
 
 // the same for the bases selected by `want` only (the children that survive): one masked popcount per base
-template <typename P>
+template <typename P, bool ONESB>
 __device__ __forceinline__ void rank_sel(const DevIndex& ix, const SbArgs& sa, RankCache& rc, u64 x, u32 want, P out[4], u32& lines) {
     rc_select(ix, rc, x, lines);
     const Blk16& r = rc.r;
@@ -99,13 +99,12 @@ __device__ __forceinline__ void rank_sel(const DevIndex& ix, const SbArgs& sa, R
     u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
     u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
     u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
-    const u64* sb = sa.one_sb ? sa.sb0 : ix.sbase + (x >> SB_SHIFT) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (!((want >> c) & 1u)) continue;
         u64 xa = ba & ((c & 2) ? r.p1a : ~r.p1a) & ((c & 1) ? r.p0a : ~r.p0a);
         u64 xb = bb & ((c & 2) ? r.p1b : ~r.p1b) & ((c & 1) ? r.p0b : ~r.p0b);
-        const u64 base = sa.one_sb ? sa.sb0[c] : sb[c];
+        const u64 base = ONESB ? sa.sb0[c] : ix.sbase[(x >> SB_SHIFT) * 4 + c];
         out[c] = (P)(base + r.cnt[c] + (u32)(__popcll(xa) + __popcll(xb)));
     }
 }
@@ -130,8 +129,8 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 // LF is monotone, so the children with symbol c of colex-ordered parents are colex-ordered among themselves and every
 // c = A child precedes every c = C child ...: the next level is the stable 4-way partition A|C|G|T of the children, and a
 // child's place is a prefix count over its symbol's bit plane -- no atomics, no allocation that can overflow.
-//   record handle of child (u, c) in a sample = c * seg + 256 * (u / 256) + rank of u among the block's parents with a child c
-// (every block of 256 parents owns 256 handles per symbol: at most one child per symbol and parent).  The trie order the
+//   record handle of child (u, c) in a sample = c * seg + 64 * (u / 64) + rank of u among its wave's parents with a child c
+// (every wave of 64 parents owns 64 handles per symbol: at most one child per symbol and parent).  The trie order the
 // reference prints in is recovered at the end of a prefix from the retained parent links, as before.
 constexpr int REC_FIELDS = 10;
 template <typename P>
@@ -176,7 +175,7 @@ struct ExpandArgs {
     u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
     SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
-    u32 access_cost[8];  // BitRank::rank calls of getL by 3-bit code
+    u32 access_pack;  // BitRank::rank calls of getL by 3-bit code, four bits each (a table in the argument block would be a load)
 };
 
 template <typename P> struct Vec4;
@@ -185,59 +184,93 @@ template <> struct Vec4<u64> { typedef ulonglong4 type; };
 
 #define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
 
-// The LF-step kernel.  One thread per node of the (colex-ordered) union level; splane receives, per wave, the four bit planes
-// "this sample keeps child c of node j" (the advance kernel derives the children's record handles from them), cnt4 (single
-// sample only: the union trie is the sample's trie) the tile's child counts per symbol for the scan.
+// The LF-step kernel.  A wave owns tiles of 64 consecutive nodes of the (colex-ordered) union level and walks them with a
+// grid stride; the waves of a launch are all resident, so the launch sweeps the level -- and with it the sample's records
+// and the index -- front to back.  While a tile is being ranked, the record heads of the wave's next tile and the handles
+// of the one after are already on their way (two-stage software pipeline), so a tile waits for one memory round trip --
+// its index blocks -- instead of three dependent ones.  Waves never synchronise with each other: a wave's children with
+// symbol c go to the 64 handles  c * seg + 64 * tile ..  of the next record buffer, ranked by ballot.
+// splane receives, per tile, the four bit planes "this sample keeps child c of node j" (the advance kernel derives the
+// children's record handles from them); cnt (single sample only: the union trie is the sample's trie) accumulates the child
+// counts per symbol and 256-node tile for the scan.
 template <typename P>
-__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                                     u64* __restrict__ splane, u32* __restrict__ cnt4, P* __restrict__ valf,
-                                                     u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
-                                                     unsigned long long* __restrict__ childmax) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    u64 n_lf = 0, n_rank = 0;
-    u32 lines = 0;
-    u32 r = DEAD;
-    if (i < a.F) r = rp[i];
+struct RecHead {   // what a lane needs of its record before anything can be ranked
+    P sp, ep, e0min, e0max;
+    u32 flags;     // bits 0-3: mask of the non-empty left-extension intervals, bit 8: the node is present in this sample
+};
+// Every load of the pipeline is unconditional (absent nodes read record 0 and discard it): a load behind a branch would make
+// the compiler wait for ALL outstanding loads at the join, and the prefetches would stop being prefetches.
+template <typename P>
+__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P>& h) {
     const bool live = r != DEAD;
-    P sp = 1, ep = 0, emin[4], emax[4];
+    const u32 rr = live ? r : 0u;
+    const P sp = rec[rr], ep = rec[cap + rr];
+    const P e0 = rec[2 * cap + rr], e1 = rec[6 * cap + rr];   // slot 0 is read whether or not it is in use: no load depends on the mask byte
+    const u32 m = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * cap)[rr];
+    h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0; h.e0min = e0; h.e0max = e1;
+    h.flags = live ? (m | 0x100u) : 0u;
+}
+
+struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
+    // (k <= 4, ne <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
+    u32 kne = 0, ll = 0, lf = 0, rank = 0;
+    bool wide = false;  // some surviving child has a frequency of 65535 or more (decides the next level's column width)
+};
+
+// One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
+// whose handles are in rn (requested one tile ago); rn then receives the handles of the tile after that.
+template <typename P, bool ONESB>
+__device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
+                                            u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf, u8* __restrict__ pl,
+                                            const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile, const RecHead<P>& hc,
+                                            RecHead<P>& hn, u32& rn, ExpandAcc& acc) {
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (1ull << lane) - 1;
+    const size_t cap = a.cap;
+    const u32 i = t * 64 + lane;
+    const bool live = (hc.flags & 0x100u) != 0;
+    const P sp = hc.sp, ep = hc.ep;
+    const u32 emask = hc.flags & 15u;
+    const u32 ne = __popc(emask);
+    // both ends of the interval are requested before anything waits (absent nodes: sp = 1, ep = 0 -> block 0, twice)
+    RankCache rc;
+    Blk16 r1;          // block of ep + 1
+    rc.bi = (u64)sp >> BLK_SHIFT;
+    const u64 b1 = ((u64)ep + 1) >> BLK_SHIFT;
+    load_blk(ix.blk, rc.bi, rc.r);
+    load_blk(ix.blk, b1, r1);
+    // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for the
+    // blocks leaves them in flight) ----
+    load_head<P>(rec, cap, rn, hn);
+    {
+        const u32 t2 = t + 2 * nwaves;
+        const u32 i2 = t2 * 64 + lane;
+        const bool in2 = t2 < ntile && i2 < a.F;
+        const u32 v = rp[in2 ? i2 : 0u];
+        rn = in2 ? v : DEAD;
+    }
+
+    u32 n_lf = 0, n_rank = 0, lines = 0;
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
-    u64 maxchild = 0; // largest frequency among the surviving children (decides the next level's column width)
     u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
-    u32 emask = 0;    // which left-extension intervals of this node are non-empty
-    u32 ne = 0;
-    RankCache rc;
-    rc.bi = ~0ull;
-    rc.b1 = ~0ull;
-    if (live) {
-        sp = rec[r];
-        ep = rec[(size_t)a.cap + r];
-        rc.bi = (u64)sp >> BLK_SHIFT;
-        rc.b1 = ((u64)ep + 1) >> BLK_SHIFT;
-        load_blk(ix.blk, rc.bi, rc.r);  // both ends of the interval are requested before anything waits
-        ++lines;
-        if (rc.b1 != rc.bi) { load_blk(ix.blk, rc.b1, rc.r1); ++lines; } else rc.b1 = ~0ull;
-        emask = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * a.cap)[r];
-        ne = __popc(emask);
-        {
-            bool matches = false;
+    u32 r = DEAD;     // this node's record handle: only the rare nodes with several left-extension intervals need it again
+    {   // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty,
+        // and straight-line code keeps the compiler from sinking the block loads behind the prefetches.
+        bool matches = ne > 0 && hc.e0min == sp && hc.e0max == ep;
+        if (ne > 1) {  // rare: more than one left-extension interval (read again by the ext pass: they are not kept in registers)
+            r = rp[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if ((u32)e < ne) {
-                    emin[e] = rec[(size_t)(2 + e) * a.cap + r];
-                    emax[e] = rec[(size_t)(6 + e) * a.cap + r];
-                    if (emin[e] == sp && emax[e] == ep) matches = true;
-                }
-            }
-            // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
-            mycode = matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u);
+            for (int e = 1; e < 4; ++e)
+                if ((u32)e < ne && rec[(size_t)(2 + e) * cap + r] == sp && rec[(size_t)(6 + e) * cap + r] == ep) matches = true;
         }
-        rank4_blk<P>(ix, a.sb, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
+        // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
+        mycode = matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u);
+        rank4_blk<P, ONESB>(ix, a.sb, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
         const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-        if (rc.b1 != ~0ull) rank4_blk<P>(ix, a.sb, rc.r1, (u64)ep + 1, Rep);  // LF(c, ep); r keeps the first block for the ext pass
-        else rank4_blk<P>(ix, a.sb, rc.r, (u64)ep + 1, Rep);
+        rank4_blk<P, ONESB>(ix, a.sb, r1, (u64)ep + 1, Rep);  // LF(c, ep); rc keeps the first block for the ext pass
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
-        if (single && a.allowed) n_rank += a.access_cost[lcode];
+        if (single && a.allowed) n_rank += (a.access_pack >> (4 * lcode)) & 15u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if ((a.allowed >> c) & 1u) {
@@ -245,50 +278,41 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                 const bool nonempty = nsp <= nep;
                 if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
                 if (nonempty) {
-                    if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (u64)(2 * ne + (single ? 2 : 0)) * a.cost[c]; }
+                    if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (2 * ne + (single ? 2 : 0)) * a.cost[c]; }
                     if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
                         present |= 1u << c;
-                        const u64 cfq = (u64)(nep - nsp) + 1;
-                        maxchild = cfq > maxchild ? cfq : maxchild;
+                        if ((u64)(nep - nsp) + 1 >= 65535) acc.wide = true;
                     }
                 }
             }
         }
+        if (!live) { n_lf = 0; n_rank = 0; present = 0; mycode = 0; }
     }
-    // ---- places of the child records: per symbol, rank of the parent inside its tile (ballots + four wave totals) ----
-    __shared__ u32 wtot[4][4];
-    __shared__ u64 red[4][NCOUNTERS];
+    {   // index lines this wave asks for at the interval ends: intervals are disjoint and increasing along the lanes, so a
+        // block is new to the wave iff it lies beyond every block of the lower lanes (lanes that share a block share the line)
+        const u32 bend = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane
+        u32 pm = bend;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
+        u32 prev = __shfl_up(pm, 1, 64);
+        if (lane == 0) prev = 0;
+        if (live) lines += ((u32)rc.bi + 1u > prev ? 1u : 0u) + ((b1 != rc.bi && (u32)b1 + 1u > prev) ? 1u : 0u);
+    }
+    // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
     const u32 k = __popc(present);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const u64 lt = (1ull << lane) - 1;
     u64 bal[4];
-    u32 excl[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        bal[c] = __ballot((present >> c) & 1u);
-        excl[c] = (u32)__popcll(bal[c] & lt);
-    }
-    if (lane < 4) {
-        const u64 b = DSM_PICK(bal, lane);
-        wtot[w][lane] = (u32)__popcll(b);
-        splane[((size_t)blockIdx.x * 4 + w) * 4 + lane] = b;
-    }
-    {
-        u64 m = maxchild;
-#pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) { u64 o = __shfl_xor(m, dd, 64); m = o > m ? o : m; }
-        if (lane == 0 && m >= 65535) atomicMax(childmax, (unsigned long long)m);  // only wide values matter (and they are rare)
-    }
-    __syncthreads();
     u32 qa[4];  // handle of this lane's child with symbol c
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        u32 off = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) off += q < w ? wtot[q][c] : 0u;
-        qa[c] = (u32)c * a.seg + blockIdx.x * TILE + off + excl[c];
+        bal[c] = __ballot((present >> c) & 1u);
+        qa[c] = (u32)c * a.seg + t * 64 + (u32)__popcll(bal[c] & lt);
     }
-    if (cnt4 && threadIdx.x < 4) cnt4[(size_t)threadIdx.x * a.nbp + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
+    if (lane < 4) {
+        const u64 b = DSM_PICK(bal, lane);
+        splane[(size_t)t * 4 + lane] = b;
+        const u32 nb = (u32)__popcll(b);
+        if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
+    }
     if (i < a.F) {
         // Child records are written child-slot by child-slot (slot j = the j-th surviving base of the lane), not base by base:
         // most nodes have one child, so a wave usually runs one pass over the fields instead of four; the lanes of a pass that
@@ -299,13 +323,13 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cj[j] = m ? (u32)__ffs(m) - 1u : 0u; m &= m - 1; qj[j] = DSM_PICK(qa, cj[j]); }
         }
-        const u32 kmax = (u32)__popcll(__ballot(k > 0)) ? (__any(k > 3) ? 4u : (__any(k > 2) ? 3u : (__any(k > 1) ? 2u : 1u))) : 0u;
+        const u32 kmax = __any(k > 0) ? (__any(k > 3) ? 4u : (__any(k > 2) ? 3u : (__any(k > 1) ? 2u : 1u))) : 0u;
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
             if (j < kmax && j < k) {
                 const u32 c = cj[j], q = qj[j];
                 out[q] = DSM_PICK(Rsp, c);
-                out[(size_t)a.cap + q] = DSM_PICK(Rep, c) - 1;
+                out[cap + q] = DSM_PICK(Rep, c) - 1;
             }
         }
         if (present) {
@@ -325,7 +349,8 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                     const u32 kk = (u32)__ffs(mm) - 1u;
                     mm &= mm - 1;
                     P lo[4] = {1, 1, 1, 1}, hi[4] = {1, 1, 1, 1};
-                    const u64 xl = (u64)emin[e], xh = (u64)emax[e] + 1;
+                    const u64 xl = e == 0 ? (u64)hc.e0min : (u64)rec[(size_t)(2 + e) * cap + r];
+                    const u64 xh = (e == 0 ? (u64)hc.e0max : (u64)rec[(size_t)(6 + e) * cap + r]) + 1;
                     if (xl == (u64)sp) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lo[c] = Rsp[c];
@@ -333,13 +358,13 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lo[c] = lastv[c];
                     } else {
-                        rank_sel<P>(ix, a.sb, rc, xl, present, lo, lines);
+                        rank_sel<P, ONESB>(ix, a.sb, rc, xl, present, lo, lines);
                     }
                     if (xh == (u64)ep + 1) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) hi[c] = Rep[c];
                     } else {
-                        rank_sel<P>(ix, a.sb, rc, xh, present, hi, lines);
+                        rank_sel<P, ONESB>(ix, a.sb, rc, xh, present, hi, lines);
                         lastx = xh;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) lastv[c] = hi[c];
@@ -350,8 +375,8 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                             const u32 c = cj[j], q = qj[j];
                             const P l = DSM_PICK(lo, c), h = DSM_PICK(hi, c);
                             if (l <= h - 1) {
-                                out[(size_t)(2 + cn[j]) * a.cap + q] = l;
-                                out[(size_t)(6 + cn[j]) * a.cap + q] = h - 1;
+                                out[(size_t)(2 + cn[j]) * cap + q] = l;
+                                out[(size_t)(6 + cn[j]) * cap + q] = h - 1;
                                 ++cn[j];
                                 cm[j] |= 1u << kk;
                             }
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
                     }
                 }
             }
-            u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * a.cap);
+            u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap);
 #pragma unroll
             for (u32 j = 0; j < 4; ++j)
                 if (j < kmax && j < k) omask[qj[j]] = (u8)cm[j];
@@ -369,20 +394,46 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
         pl[i] = (u8)(present | (mycode << 4));
     }
-    // counters (exact; the block lines include the ones the ext pass fetched).  They travel as two packed words:
-    // per lane k <= 4, ne <= 4, live <= 1, lines <= 12, lf <= 40, rank-ops <= a few hundred
-    u64 packed = (u64)k | ((u64)ne << 10) | ((u64)(live ? 1u : 0u) << 20) | ((u64)lines << 30);
-    u64 packed2 = n_lf | (n_rank << 24);
-    packed = wave_sum_u64(packed);
-    packed2 = wave_sum_u64(packed2);
-    if (lane == 0) {
-        red[w][0] = packed & 0x3FF; red[w][4] = (packed >> 10) & 0x3FF; red[w][5] = (packed >> 20) & 0x3FF; red[w][3] = packed >> 30;
-        red[w][1] = packed2 & 0xFFFFFF; red[w][2] = packed2 >> 24;
+    acc.kne += k | (ne << 16); acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
+}
+
+template <typename P, bool ONESB>
+__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
+                                                     u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
+                                                     u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
+                                                     unsigned long long* __restrict__ childmax) {
+    const int lane = threadIdx.x & 63;
+    const u32 nwaves = gridDim.x * 4;
+    const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 ntile = (a.F + 63) >> 6;
+    ExpandAcc acc;
+    // prologue of the pipeline: heads of the wave's first tile, handles of its second
+    u32 rn = DEAD;
+    {
+        u32 r0 = DEAD;
+        const u32 i0 = gw * 64 + lane, i1 = (gw + nwaves) * 64 + lane;
+        if (gw < ntile && i0 < a.F) r0 = rp[i0];
+        if (gw + nwaves < ntile && i1 < a.F) rn = rp[i1];
+        RecHead<P> hA, hB;
+        load_head<P>(rec, a.cap, r0, hA);
+        // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
+        for (u32 t = gw; t < ntile; t += 2 * nwaves) {
+            expand_tile<P, ONESB>(ix, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc);
+            if (t + nwaves < ntile) expand_tile<P, ONESB>(ix, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc);
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < NCOUNTERS) {
-        u64 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (t) atomicAdd((unsigned long long*)&counters[(size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * 8 + threadIdx.x], (unsigned long long)t);
+    // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
+    if (__any(acc.wide) && lane == 0) atomicMax(childmax, 65535ull);  // only "65535 or more" matters (and it is rare)
+    {
+        u64 v[NCOUNTERS] = {acc.kne & 0xFFFFu, acc.lf, acc.rank, acc.ll >> 16, acc.kne >> 16, acc.ll & 0xFFFFu};
+#pragma unroll
+        for (int q = 0; q < NCOUNTERS; ++q) v[q] = wave_sum_u64(v[q]);
+        if (lane < NCOUNTERS) {
+            u64 mine = v[0];
+#pragma unroll
+            for (int q = 1; q < NCOUNTERS; ++q) mine = lane == q ? v[q] : mine;
+            if (mine) atomicAdd((unsigned long long*)&counters[(size_t)(gw & (COUNTER_SHARDS - 1)) * 8 + lane], (unsigned long long)mine);
+        }
     }
 }
 
@@ -487,6 +538,7 @@ struct AdvanceOut {
     u64* kplane_w;       // where the level's retained directory keeps them (null: kplane already is that array)
     u32* kcum;           // retained directory counts, per wave (written here)
     const u32* cnt4;     // scanned tile offsets [4][nbp] (unused by a single-tile level)
+    u32* cnt_clear;      // single sample: the raw tile counts the expand kernel accumulated (cleared here for the next level)
     u32 nbp;
     const u16* sinfo;    // per-slot sample counts from the reduce pass (null: d == 1, or the single tile evaluates the columns itself)
     u32 eval;            // single tile, more than one sample: evaluate the union from the exchanged columns here
@@ -542,8 +594,9 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
 #pragma unroll
         for (int c = 0; c < 4; ++c) up[c] = __ballot(nT4[c] != 0);
     } else {
+        const bool inside = wv * 64 < F;  // the expand kernel writes planes for the waves that hold nodes only
 #pragma unroll
-        for (int c = 0; c < 4; ++c) up[c] = o.kplane[wv * 4 + c];
+        for (int c = 0; c < 4; ++c) up[c] = inside ? o.kplane[wv * 4 + c] : 0ull;
         if (o.sinfo) {
             if (u < F) {
                 const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
@@ -575,6 +628,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
         total = base;
     }
     if (lane < 4) o.kcum[wv * 4 + lane] = DSM_PICK(cum, lane);
+    if (o.cnt_clear && threadIdx.x < 4) o.cnt_clear[(size_t)threadIdx.x * o.nbp + blockIdx.x] = 0;  // the expand kernels of the next level add into it
     if (u < F) {
         u32 pres = 0, lastT = 0, vj[4];
 #pragma unroll
@@ -600,14 +654,12 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
                 for (int c = 0; c < 4; ++c)
                     if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
             } else {       // index: the place the sample's expand kernel gave the child (see the record layout)
-                const u64* sp = o.splane[sl] + (size_t)blockIdx.x * 16;
+                const u64* sp = o.splane[sl] + wv * 4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
-                    const u64 mine = sp[w * 4 + c];
-                    u32 off = 0;
-                    for (u32 q = 0; q < w; ++q) off += (u32)__popcll(sp[q * 4 + c]);
-                    rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + blockIdx.x * TILE + off + (u32)__popcll(mine & lt) : DEAD;
+                    const u64 mine = sp[c];
+                    rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + (u32)wv * 64u + (u32)__popcll(mine & lt) : DEAD;
                 }
             }
         }
@@ -1407,7 +1459,9 @@ class Engine {
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
     u64 bpr_cap = 0;
-    u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced, scanned in place
+    u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced -> scanned offsets
+    u32* cntraw = nullptr;                     // single sample: the counts as the expand kernel accumulates them (kept zero between levels)
+    u32 expand_blocks = 1024;                  // resident blocks of the LF-step kernel (its waves walk the level with a grid stride)
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8* samechild = nullptr;
@@ -1570,6 +1624,18 @@ class Engine {
         if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
         if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
+        if (d == 1 && !trie_mode) {
+            if (int rc = dalloc(cntraw, 4 * ntile + 8)) return rc;
+            DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
+        }
+        {   // all waves of an LF-step launch are resident: blocks = CUs x blocks per CU at the kernel's register footprint
+            int cus = 0, per = 0;
+            DSM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            DSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, expand_kernel<P, true>, 256, 0));
+            if (const char* e = getenv("DSM_EXPAND_BLOCKS_PER_CU")) per = atoi(e);
+            if (per < 1) per = 1;
+            expand_blocks = (u32)(cus > 0 ? cus : 256) * (u32)per;
+        }
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
@@ -1685,6 +1751,7 @@ class Engine {
         std::vector<LevelHost> L;
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
+        if (cntraw) DSM_HIP(hipMemsetAsync(cntraw, 0, (4 * (size_t)(Seg / TILE) + 8) * sizeof(u32), st));  // a run that failed mid-level may have left counts
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -1791,13 +1858,25 @@ class Engine {
             for (int s = 0; s < nlocal && !trie_mode; ++s) {
                 const IndexMeta& m = idx[s]->meta;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
-                ea.sb.one_sb = (m.n >> SB_SHIFT) == 0 ? 1u : 0u;
+                const bool one_sb = (m.n >> SB_SHIFT) == 0;
                 for (int c = 0; c < 4; ++c) ea.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
-                for (int c = 0; c < 8; ++c) ea.access_cost[c] = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
+                ea.access_pack = 0;
+                for (int c = 0; c < 8; ++c) {
+                    const u32 bits = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
+                    if (bits > 15) return fail(DSM_E_UNSUPPORTED, "Huffman code longer than 15 bits");
+                    ea.access_pack |= bits << (4 * c);
+                }
                 P* cf = reinterpret_cast<P*>(send + XHDR + (size_t)s * F * fb);           // this sample's frequency column
                 u8* cl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;           // children nibble | left char << 4
-                hipLaunchKernelGGL((expand_kernel<P>), grid_for(F), dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s],
-                                   (d == 1 && ea.nbp > 1) ? cnt4 : (u32*)nullptr, cf, cl, ea, d_counters, d_childmax);
+                const u32 need = (F + TILE - 1) / TILE;
+                const dim3 eg(need < expand_blocks ? need : expand_blocks);
+                u32* ecnt = (d == 1 && ea.nbp > 1) ? cntraw : (u32*)nullptr;
+                if (one_sb)
+                    hipLaunchKernelGGL((expand_kernel<P, true>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, cf, cl,
+                                       ea, d_counters, d_childmax);
+                else
+                    hipLaunchKernelGGL((expand_kernel<P, false>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, cf, cl,
+                                       ea, d_counters, d_childmax);
                 ++stats.expand_launches;
                 stats.expand_slots += F;
                 stats.expand_column_bytes += (u64)F * (fb + 1);
@@ -1866,7 +1945,10 @@ class Engine {
             } else {                   // one sample: the union trie is its trie, the expand kernel wrote planes and tile counts
                 ao.kplane = splane[0]; ao.kplane_w = me.kplane;
             }
-            if (nbp > 1) exclusive_scan<u32, u32>(cnt4, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
+            if (nbp > 1) {
+                exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
+                if (!merged) ao.cnt_clear = cntraw;
+            }
             hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
