@@ -158,6 +158,19 @@ __device__ __forceinline__ u32 kid_index(const Kids& k, u32 v, u32 c) {
     return k.cum[e] + (u32)__popcll(k.plane[e] & ((1ull << (v & 63)) - 1));
 }
 
+// The directory words of a wave's 64 nodes, fetched once per wave (w is wave-uniform: scalar loads) instead of once per lane.
+struct KidWave {
+    u64 p[4];
+    u32 c[4];
+};
+__device__ __forceinline__ void kid_wave(const Kids& k, u32 w, KidWave& o) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { o.p[c] = k.plane[(size_t)w * 4 + c]; o.c[c] = k.cum[(size_t)w * 4 + c]; }
+}
+__device__ __forceinline__ u32 bits_below_lane(u64 p) {  // set bits of p below this lane's position
+    return __builtin_amdgcn_mbcnt_hi((u32)(p >> 32), __builtin_amdgcn_mbcnt_lo((u32)p, 0u));
+}
+
 // Thread-per-node kernels do little per node; a thread takes NPT nodes a grid-width apart (coalescing is kept) and issues
 // all their loads before using any, so a wave has several lines in flight and the grid is NPT times smaller.
 constexpr int NPT = 4;
@@ -542,6 +555,7 @@ struct AdvanceOut {
     u32 nbp;
     const u16* sinfo;    // per-slot sample counts from the reduce pass (null: d == 1, or the single tile evaluates the columns itself)
     u32 eval;            // single tile, more than one sample: evaluate the union from the exchanged columns here
+    u32 single;          // one sample in all (index mode): no reader counts, its planes are the union's planes
     // per local sample record handles
     u32* const* rp;             // device table of nlocal pointers: handles of the new level
     const u64* const* splane;   // per local sample: the planes its expand kernel wrote (index mode)
@@ -637,12 +651,12 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
             if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
         }
         const u32 nc = __popc(pres);
-        o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+        if (!o.single) o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;  // (a single sample: always 1 reader, nobody reads these)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (((pres >> c) & 1u) && vj[c] < o.cap) {  // a level wider than its arrays is reported through the total, not written
                 o.slot[vj[c]] = 4u * u + (u32)c;
-                o.nT[vj[c]] = (u16)nT4[c];
+                if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
             }
         }
         for (u32 sl = 0; sl < o.nlocal && pres; ++sl) {  // record handles of this parent's children in every local sample
@@ -654,11 +668,11 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
                 for (int c = 0; c < 4; ++c)
                     if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
             } else {       // index: the place the sample's expand kernel gave the child (see the record layout)
-                const u64* sp = o.splane[sl] + wv * 4;
+                const u64* sp = o.single ? o.kplane + wv * 4 : o.splane[sl] + wv * 4;  // single sample: its planes are the union's
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
-                    const u64 mine = sp[c];
+                    const u64 mine = o.single ? up[c] : sp[c];
                     rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + (u32)wv * 64u + (u32)__popcll(mine & lt) : DEAD;
                 }
             }
@@ -775,16 +789,24 @@ constexpr double ENT_MARGIN = 1e-4;
 template <typename P>
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, Kids kids,
                                                      const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
-    const u32 stride = gridDim.x * blockDim.x;
-    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const bool one = a.d == 1;  // a single sample: every node has one reader, a single child always carries it
     u32 t[NPT];
     bool out[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {  // the cheap predicates of all NPT nodes first: their loads are in flight together
-        const u32 v = v0 + i * stride, vc = v < a.F ? v : 0u;
-        t[i] = nT[vc];
-        const u32 nc = __popc(kid_mask(kids, vc));
-        const u32 same = samechild[vc];
+        const u32 w = w0 + (u32)i * stride;
+        const u32 v = w * 64 + lane, vc = v < a.F ? v : 0u;
+        t[i] = one ? 1u : (u32)nT[vc];
+        u32 nc = 0;
+        if (w < nw) {
+            KidWave kw;
+            kid_wave(kids, w, kw);
+            nc = (u32)((kw.p[0] >> lane) & 1) + (u32)((kw.p[1] >> lane) & 1) + (u32)((kw.p[2] >> lane) & 1) + (u32)((kw.p[3] >> lane) & 1);
+        }
+        const u32 same = one ? 1u : (u32)samechild[vc];
         bool o = v < a.F;
         if (a.depth < a.mindepth) o = false;
         if (a.pmax != 0 && t[i] > a.pmax) o = false;
@@ -794,7 +816,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const
     }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 v = v0 + i * stride;
+        const u32 v = (w0 + (u32)i * stride) * 64 + lane;
         if (out[i]) {  // merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
             u64 sumN = a.d;
             double s = 0;
@@ -874,76 +896,82 @@ __global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict_
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
-// bottom-up: agg[v] = own[v] + sum over children agg_child          (children of v: kid_index(kids, v, c) for c in kid_mask)
+// A wave takes 64 consecutive nodes (and NPT such groups a grid-width apart): the directory words are wave-uniform.
+// bottom-up: agg[v] = own[v] + sum over children agg_child
 template <typename T, typename OwnT>
 __global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__ own, Kids kids, const T* __restrict__ child_agg,
                                                  T* __restrict__ agg) {
-    const u32 stride = gridDim.x * blockDim.x;
-    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 m[NPT];
-    T s[NPT];
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
-        m[i] = v < F && child_agg ? kid_mask(kids, vc) : 0u;
-        s[i] = own ? (T)own[vc] : (T)1;
-    }
+        const u32 w = w0 + (u32)i * stride;
+        if (w >= nw) break;
+        const u32 v = w * 64 + lane;
+        T s = v < F ? (own ? (T)own[v] : (T)1) : (T)0;
+        if (child_agg) {
+            KidWave kw;
+            kid_wave(kids, w, kw);
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const u32 v = v0 + i * stride;
-#pragma unroll
-        for (u32 c = 0; c < 4; ++c)
-            if ((m[i] >> c) & 1u) s[i] += child_agg[kid_index(kids, v, c)];
-        if (v < F) agg[v] = s[i];
+            for (int c = 0; c < 4; ++c)
+                if ((kw.p[c] >> lane) & 1) s += child_agg[kw.c[c] + bits_below_lane(kw.p[c])];
+        }
+        if (v < F) agg[v] = s;
     }
 }
 // top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]   (children in A,C,G,T order)
 template <typename T>
 __global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ start, T lead, Kids kids,
                                                    const T* __restrict__ child_agg, T* __restrict__ child_start) {
-    const u32 stride = gridDim.x * blockDim.x;
-    const u32 v0 = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 m[NPT];
-    T s[NPT];
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 v = v0 + i * stride, vc = v < F ? v : 0u;
-        m[i] = v < F ? kid_mask(kids, vc) : 0u;
-        s[i] = start[vc] + lead;
-    }
+        const u32 w = w0 + (u32)i * stride;
+        if (w >= nw) break;
+        const u32 v = w * 64 + lane;
+        KidWave kw;
+        kid_wave(kids, w, kw);
+        T s = (v < F ? start[v] : (T)0) + lead;
+        const u32 m = (u32)((kw.p[0] >> lane) & 1) | ((u32)((kw.p[1] >> lane) & 1) << 1) | ((u32)((kw.p[2] >> lane) & 1) << 2) |
+                      ((u32)((kw.p[3] >> lane) & 1) << 3);
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const u32 v = v0 + i * stride;
-#pragma unroll
-        for (u32 c = 0; c < 4; ++c) {
-            if ((m[i] >> c) & 1u) {
-                const u32 ch = kid_index(kids, v, c);
-                child_start[ch] = s[i];
-                if (m[i] >> (c + 1)) s[i] += child_agg[ch];  // only when a later sibling exists
+        for (int c = 0; c < 4; ++c) {
+            if ((m >> c) & 1u) {
+                const u32 ch = kw.c[c] + bits_below_lane(kw.p[c]);
+                child_start[ch] = s;
+                if (m >> (c + 1)) s += child_agg[ch];  // only when a later sibling exists
             }
         }
     }
 }
 
-// candidate k of a level gets its post-order rank among all candidates of the chunk
-__global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, const u32* __restrict__ start, const u32* __restrict__ sub,
-                                 u32 level, u32* __restrict__ t_level, u32* __restrict__ t_cidx) {
+// candidate k of a level gets its post-order rank among all candidates of the prefix; the tuple's sizes go to their place
+// in output order (the ranks of neighbouring candidates are far apart: the levels are in colex order, the output in trie order)
+__global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, const u32* __restrict__ cand_poff, u32 npairs,
+                                 const u32* __restrict__ start, const u32* __restrict__ sub, u32 level, u32* __restrict__ crank,
+                                 u32* __restrict__ plen, u32* __restrict__ npair) {
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncand) return;
     u32 v = cand_node[k];
     u32 r = start[v] + sub[v] - 1;
-    t_level[r] = level;
-    t_cidx[r] = k;
+    crank[k] = r;
+    plen[r] = level;
+    npair[r] = (k + 1 < ncand ? cand_poff[k + 1] : npairs) - cand_poff[k];
 }
 
 struct LevelDev {
     const u32* slot;
     const u32* cand_node;
     const u32* cand_poff;
+    const u32* crank;   // post-order rank of candidate k
     const u32* ids;
     const u64* freqs;
     u32 ncand;
     u32 npairs;
+    u32 cbase;          // candidates of the shallower levels
 };
 
 // offsets of the chunk boundaries (path bytes, pairs) for the host: out[2c], out[2c+1] for boundary tuple tb[c]
@@ -954,36 +982,40 @@ __global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ pat
     if (c <= cbs.n) { out[2 * c] = path_off[cbs.tb[c]]; out[2 * c + 1] = pair_off[cbs.tb[c]]; }
 }
 
-__global__ void tuple_size_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
-                                  u32* __restrict__ plen, u32* __restrict__ npair) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nt) return;
-    const LevelDev L = lv[t_level[r]];
-    u32 k = t_cidx[r];
-    u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
-    plen[r] = t_level[r];
-    npair[r] = e - L.cand_poff[k];
-}
-
-__global__ void tuple_fill_kernel(u32 nt, const LevelDev* __restrict__ lv, const u32* __restrict__ t_level, const u32* __restrict__ t_cidx,
-                                  const u32* __restrict__ path_off, const u32* __restrict__ pair_off, char* __restrict__ paths,
-                                  u32* __restrict__ ids, u64* __restrict__ freqs, u32 r0) {
-    u32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x;  // tuples [r0, nt)
-    if (r >= nt) return;
-    u32 lvl = t_level[r];
+// Paths and pairs of all tuples.  Threads take the candidates level by level in node order: the nodes of neighbouring lanes
+// are neighbours in their level, and so are their ancestors all the way up (children with the same symbol keep the order of
+// their parents), so every step of the walk reads neighbouring links.  A lane gathers four symbols before it stores them.
+__global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const LevelDev* __restrict__ lv, const u32* __restrict__ path_off,
+                                                         const u32* __restrict__ pair_off, char* __restrict__ paths, u32* __restrict__ ids,
+                                                         u64* __restrict__ freqs) {
+    const u32 f = blockIdx.x * blockDim.x + threadIdx.x;  // candidates in level-major order
+    if (f >= nt) return;
+    u32 lo = 1, hi = nlev - 1;  // the level whose candidates include f: largest l with cbase[l] <= f among the levels that have any
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (lv[mid].cbase <= f) lo = mid; else hi = mid - 1;
+    }
+    const u32 lvl = lo;
     const LevelDev L = lv[lvl];
-    u32 k = t_cidx[r];
-    u32 b = L.cand_poff[k];
-    u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
+    const u32 k = f - L.cbase;
+    const u32 r = L.crank[k];
+    const u32 b = L.cand_poff[k];
+    const u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
     u32 o = pair_off[r];
     for (u32 q = b; q < e; ++q, ++o) { ids[o] = L.ids[q]; freqs[o] = L.freqs[q]; }
     u32 v = L.cand_node[k];
-    u32 po = path_off[r];
+    char* dst = paths + path_off[r];
+    u32 word = 0, have = 0;
     for (u32 l = lvl; l >= 1; --l) {
-        u32 s = lv[l].slot[v];
-        paths[po + l - 1] = "ACGT"[s & 3];
-        v = s >> 2;
+        const u32 sl = lv[l].slot[v];
+        word = (word << 8) | ((0x54474341u >> (8 * (sl & 3))) & 0xFFu);  // "ACGT"[sym]: the lowest character so far goes to the lowest byte
+        v = sl >> 2;
+        if (++have == 4) {
+            __builtin_memcpy(dst + l - 1, &word, 4);
+            have = 0;
+        }
     }
+    for (u32 q = 0; q < have; ++q) dst[q] = (char)(word >> (8 * q));
 }
 
 // ---- wire stream (ClientSocket.h:20-39) ---------------------------------------------------------
@@ -1943,7 +1975,7 @@ class Engine {
                 hipLaunchKernelGGL((advance_reduce_kernel<P>), dim3(nbp), dim3(256), 0, st, x, sinfo, me.kplane, cnt4, nbp);
                 ao.kplane = me.kplane; ao.sinfo = sinfo;
             } else {                   // one sample: the union trie is its trie, the expand kernel wrote planes and tile counts
-                ao.kplane = splane[0]; ao.kplane_w = me.kplane;
+                ao.kplane = splane[0]; ao.kplane_w = me.kplane; ao.single = 1;
             }
             if (nbp > 1) {
                 exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
@@ -2023,7 +2055,7 @@ class Engine {
                 capture->ord.clear();
                 for (u32 v = 0; v < Fn; ++v) {
                     capture->sym.push_back(hs[v] & 3);
-                    std::vector<u16> o(hn[v]);
+                    std::vector<u16> o(d == 1 ? 1 : hn[v]);  // (a single sample keeps no reader counts)
                     if (order_mode == 1) {
                         u64 ord = 0;
                         DSM_HIP(hipMemcpy(&ord, order[nxt] + v, sizeof(u64), hipMemcpyDeviceToHost));
@@ -2165,29 +2197,35 @@ class Engine {
             }
             hipLaunchKernelGGL((up_kernel<u32, u8>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].kids(), child_sub, L[l].sub);
         }
-        // top-down: start offsets, two rolling arrays
-        u32 *t_level, *t_cidx;
-        EARENA_GET(t_level, u32, nt);
-        EARENA_GET(t_cidx, u32, nt);
+        // top-down: start offsets (two rolling arrays); every candidate's post-order rank, and its sizes at that rank
+        u32 *plen, *npair;
+        EARENA_GET(plen, u32, nt);
+        EARENA_GET(npair, u32, nt);
         u32 maxn = 1;
         for (u32 l = 0; l < nlev; ++l) maxn = L[l].n > maxn ? L[l].n : maxn;
         u32* startbuf[2];
         EARENA_GET(startbuf[0], u32, maxn);
         EARENA_GET(startbuf[1], u32, maxn);
+        std::vector<u32*> crank(nlev, nullptr);
+        for (u32 l = 1; l < nlev; ++l)
+            if (L[l].ncand) EARENA_GET(crank[l], u32, L[l].ncand);
         DSM_HIP(hipMemsetAsync(startbuf[0], 0, sizeof(u32), st));
         for (u32 l = 0; l + 1 < nlev; ++l) {
             u32* s_cur = startbuf[l & 1];
             u32* s_next = startbuf[(l + 1) & 1];
             hipLaunchKernelGGL((down_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].kids(), L[l + 1].sub, s_next);
             if (L[l + 1].ncand)
-                hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, s_next, L[l + 1].sub, l + 1,
-                                   t_level, t_cidx);
+                hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, L[l + 1].cand_poff,
+                                   L[l + 1].npairs, s_next, L[l + 1].sub, l + 1, crank[l + 1], plen, npair);
         }
         // tuple sizes -> offsets
         std::vector<LevelDev> lv(nlev);
+        u32 cb = 0;
         for (u32 l = 0; l < nlev; ++l) {
-            lv[l].slot = L[l].slot; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff;
-            lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = L[l].ncand; lv[l].npairs = L[l].npairs;
+            lv[l].slot = L[l].slot; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff; lv[l].crank = crank[l];
+            lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = l ? L[l].ncand : 0; lv[l].npairs = L[l].npairs;
+            lv[l].cbase = cb;
+            cb += lv[l].ncand;
         }
         LevelDev* d_lv;
         EARENA_GET(d_lv, LevelDev, nlev);
@@ -2198,14 +2236,10 @@ class Engine {
         E.device = device;
         if (!E.ready) DSM_HIP(hipEventCreateWithFlags(&E.ready, hipEventDisableTiming));
         if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        u32 *plen, *npair;
-        EARENA_GET(plen, u32, nt);
-        EARENA_GET(npair, u32, nt);
         if (int rc = E.dev[0].ensure(((size_t)nt + 1) * 4)) return rc;
         if (int rc = E.dev[1].ensure(((size_t)nt + 1) * 4)) return rc;
         u32* path_off = (u32*)E.dev[0].p;
         u32* pair_off = (u32*)E.dev[1].p;
-        hipLaunchKernelGGL(tuple_size_kernel, grid_for(nt), dim3(256), 0, st, nt, d_lv, t_level, t_cidx, plen, npair);
         u32* stmp;
         EARENA_GET(stmp, u32, scan_tmp_elems(nt) + 8);
         exclusive_scan<u32, u32>(plen, path_off, nt, stmp, d_totals, st);
@@ -2235,17 +2269,17 @@ class Engine {
         if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
         if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
         E.nchunk = cbs.n;
-        for (int c = 0; c < cbs.n; ++c) {  // fill, copy and signal chunk by chunk
+        // one fill for the whole prefix (its threads follow the levels, not the output order); the copies and the host's work
+        // stay chunked by output rank
+        hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs);
+        DSM_HIP(hipGetLastError());
+        if (!chunk_filled[0]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[0], hipEventDisableTiming));
+        DSM_HIP(hipEventRecord(chunk_filled[0], st));
+        DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[0], 0));
+        for (int c = 0; c < cbs.n; ++c) {  // copy and signal chunk by chunk
             const u32 t0 = cbs.tb[c], t1 = cbs.tb[c + 1];
             E.cb[c] = t0; E.cb[c + 1] = t1;
             if (!E.cready[c]) DSM_HIP(hipEventCreateWithFlags(&E.cready[c], hipEventDisableTiming));
-            if (!chunk_filled[c]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[c], hipEventDisableTiming));
-            if (t1 > t0) {
-                hipLaunchKernelGGL(tuple_fill_kernel, grid_for(t1 - t0), dim3(256), 0, st, t1, d_lv, t_level, t_cidx, path_off, pair_off, d_paths, d_ids, d_freqs, t0);
-                DSM_HIP(hipGetLastError());
-            }
-            DSM_HIP(hipEventRecord(chunk_filled[c], st));
-            DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
             const u64 pb0 = h_totals[16 + 2 * c], qb0 = h_totals[17 + 2 * c], pb1 = h_totals[16 + 2 * (c + 1)], qb1 = h_totals[17 + 2 * (c + 1)];
             // boundary entries are shared by neighbouring chunks: both copy the same value
             DSM_HIP(hipMemcpyAsync((u32*)E.pin[0].p + t0, path_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdsmhip.so")
+LIB_PATH = os.environ.get("DSM_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libdsmhip.so")  # (override: profiling variants)
 
 LAYOUT_PLANES = 0
 LAYOUT_WT = 1
