@@ -558,15 +558,13 @@ struct AdvanceOut {
     u32 single;          // one sample in all (index mode): no reader counts, its planes are the union's planes
     // per local sample record handles
     u32* const* rp;             // device table of nlocal pointers: handles of the new level
+    u32* rp0;                   // the same for the single sample of a one-sample run (no table to read first)
     const u64* const* splane;   // per local sample: the planes its expand kernel wrote (index mode)
     const u32* const* tpos;     // trie mode: handle of the first allowed child in the parsed stream
     u32 nlocal, rank;
     u32 seg;           // handles per symbol segment of the record buffers
     u32 cap;           // entries of the new level's arrays: a wider level is reported through the total, not written
-    // what the host needs after the level, gathered by the last block (publish_kernel hands it to the host):
-    const u32* d_total;  // grand total of the scan (more than one tile)
-    u32* h_totals;       // [0] = nodes of the new level
-    u64* h_childmax;     // [r] = largest child frequency reported by rank r
+    u32* h_totals;       // single-tile levels: [0] = nodes of the new level (larger levels: the grand total of the scan)
 };
 
 // The few words the host reads after a level go to pinned host memory in one tiny launch.  A large kernel that wrote them
@@ -575,11 +573,18 @@ struct PublishArgs {
     const u32* src[4];
     u32* dst[4];
     u32 words[4];
+    const u8* cmax_base;  // exchange buffer of the level: rank r's message starts with the largest child frequency it saw
+    u64 cmax_bpr;
+    u64* cmax_dst;        // pinned, one per rank
+    u32 cmax_world;
     u32* clear;   // header of the message the next level's expand kernels will fill (4 words), may be null
     u32* flag;    // pinned: receives `seq` after everything above is visible to the host (the host spins on it)
     u32 seq;
 };
 __global__ void publish_kernel(PublishArgs a) {
+    for (u32 r = threadIdx.x; r < a.cmax_world; r += blockDim.x)
+        a.cmax_dst[r] = *reinterpret_cast<const u64*>(a.cmax_base + (u64)r * a.cmax_bpr);
+    __syncthreads();  // (the header that is cleared next may be the one just read: single process, alternating buffers do not alias, but keep the order)
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -678,11 +683,89 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x == 0) o.h_totals[0] = gridDim.x == 1 ? total : *o.d_total;
-        const u32 world = x.d / x.nlocal;
-        for (u32 r = threadIdx.x; r < world; r += blockDim.x)
-            o.h_childmax[r] = *reinterpret_cast<const u64*>(x.base + (u64)r * x.bpr);
+    if (threadIdx.x == 0) o.h_totals[0] = total;  // (this kernel runs single-tile levels only)
+}
+
+// The same down-sweep for levels of more than one tile, wave by wave with no block-level step: a wave takes 64 parents (and NPT
+// such groups a grid-width apart, all their directory words requested up front); its place inside its 256-parent tile comes
+// from the planes of the tile's earlier waves, the tile's place from the scanned counts.
+template <typename P>
+__global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o) {
+    const u32 F = (u32)x.F;
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u64 lt = (1ull << lane) - 1;
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+        const u32 w = w0 + (u32)it * stride;
+        if (w >= nw) break;
+        const u32 tile = w >> 2, wi = w & 3;
+        const u32 u = w * 64 + lane;
+        u64 up[4];
+        u32 cum[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            up[c] = o.kplane[(size_t)w * 4 + c];
+            u32 before = 0;
+            for (u32 q = 0; q < wi; ++q) before += (u32)__popcll(o.kplane[((size_t)tile * 4 + q) * 4 + c]);
+            cum[c] = o.cnt4[(size_t)c * o.nbp + tile] + before;
+        }
+        u32 nT4[4] = {0, 0, 0, 0};
+        if (o.sinfo) {
+            if (u < F) {
+                const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
+                nT4[0] = q.x & 0xFFFFu; nT4[1] = q.x >> 16; nT4[2] = q.y & 0xFFFFu; nT4[3] = q.y >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nT4[c] = (u32)((up[c] >> lane) & 1);
+        }
+        if (lane < 4) {
+            o.kcum[(size_t)w * 4 + lane] = DSM_PICK(cum, lane);
+            if (o.kplane_w) o.kplane_w[(size_t)w * 4 + lane] = DSM_PICK(up, lane);
+            if (o.cnt_clear && wi == 0) o.cnt_clear[(size_t)lane * o.nbp + tile] = 0;  // the expand kernels of the next level add into it
+        }
+        if (u >= F) continue;
+        u32 pres = 0, lastT = 0, vj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vj[c] = cum[c] + (u32)__popcll(up[c] & lt);
+            if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
+        }
+        const u32 nc = __popc(pres);
+        if (!o.single) o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (((pres >> c) & 1u) && vj[c] < o.cap) {
+                o.slot[vj[c]] = 4u * u + (u32)c;
+                if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
+            }
+        }
+        if (o.single) {  // one sample: its planes are the union's, its handle table is passed directly
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (((pres >> c) & 1u) && vj[c] < o.cap) o.rp0[vj[c]] = (u32)c * o.seg + w * 64u + (u32)__popcll(up[c] & lt);
+            continue;
+        }
+        for (u32 sl = 0; sl < o.nlocal && pres; ++sl) {
+            u32* rp = o.rp[sl];
+            if (o.tpos) {
+                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
+                const u32 h = m ? o.tpos[sl][u] : 0u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+            } else {
+                const u64* sp = o.splane[sl] + (size_t)w * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
+                    const u64 mine = sp[c];
+                    rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + w * 64u + (u32)__popcll(mine & lt) : DEAD;
+                }
+            }
+        }
     }
 }
 
@@ -785,10 +868,11 @@ struct FilterArgs {
 // The device value uses the hardware log2 (v_log_f32, 1 ulp: at most 2^-18 absolute for arguments below 2^64), so it
 // is off by less than 1e-5; the margin leaves a factor of ten.
 constexpr double ENT_MARGIN = 1e-4;
-// key[v] = candidate flag in the low word, number of pairs in the high word (one fused scan).
+// Per wave of 64 nodes: candbits[w] = which of them are candidates, wsum[w] = their number (low word) and their number of
+// (id, freq) pairs (high word); a scan over the waves gives every wave the place of its first candidate.
 template <typename P>
 __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, Kids kids,
-                                                     const u8* __restrict__ samechild, u8* __restrict__ cand, u64* __restrict__ key) {
+                                                     const u8* __restrict__ samechild, u64* __restrict__ candbits, u64* __restrict__ wsum) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
     const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -816,7 +900,8 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const
     }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 v = (w0 + (u32)i * stride) * 64 + lane;
+        const u32 w = w0 + (u32)i * stride;
+        const u32 v = w * 64 + lane;
         if (out[i]) {  // merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
             u64 sumN = a.d;
             double s = 0;
@@ -836,54 +921,57 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const
                 if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) out[i] = false;
             }
         }
-        if (v < a.F) {
-            cand[v] = out[i] ? 1 : 0;
-            if (key) key[v] = out[i] ? (1ull | ((u64)t[i] << 32)) : 0ull;  // d == 1: one pair per candidate, the flag scan is enough
+        if (w < nw) {
+            const u64 bits = __ballot(out[i]);
+            u64 pairs = (u64)__popcll(bits);
+            if (!one) pairs = wave_sum_u64(out[i] ? (u64)t[i] : 0ull);
+            if (lane == 0) { candbits[w] = bits; wsum[w] = (u64)__popcll(bits) | (pairs << 32); }
         }
     }
 }
 
 // store the candidates of a level: node index and (id, freq) pairs in the reference's iteration order
 template <typename P>
-__global__ void cand_store_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order,
-                                  const u16* __restrict__ order16, const u8* __restrict__ cand, const u64* __restrict__ keyscan,
-                                  const u32* __restrict__ idx32,
-                                  u32* __restrict__ cand_node, u32* __restrict__ cand_poff, u32* __restrict__ ids, u64* __restrict__ freqs) {
-    // a thread looks at eight consecutive flags with one load (few nodes are candidates: a thread per node is mostly idle)
-    const u32 v8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
-    if (v8 >= a.F) return;
-    u64 flags = 0;
-    if (v8 + 8 <= a.F) flags = *reinterpret_cast<const u64*>(cand + v8);
-    else for (u32 q = 0; v8 + q < a.F; ++q) flags |= (u64)cand[v8 + q] << (8 * q);
-    while (flags) {
-    const u32 v = v8 + (u32)((__ffsll((long long)flags) - 1) >> 3);
-    flags &= flags - 1;  // flags are 0 or 1 per byte
-    const u32 k = keyscan ? (u32)(keyscan[v] & 0xFFFFFFFFu) : idx32[v];
-    u32 o = keyscan ? (u32)(keyscan[v] >> 32) : k;
-    cand_node[k] = v;
-    cand_poff[k] = o;
-    const u64 j = v;
-    if (a.exact_order == 1) {
-        const u64 ord = order[v];
-        const u32 cnt = nT[v];
-        for (u32 q = 0; q < cnt; ++q) {
-            u32 g = (u32)((ord >> (4 * q)) & 15);
-            ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
-        }
-    } else if (a.exact_order == 2) {
-        const u16* ord = order16 + (size_t)v * a.d;
-        const u32 cnt = nT[v];
-        for (u32 q = 0; q < cnt; ++q) {
-            u32 g = ord[q];
-            ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
-        }
-    } else {
-        for (u32 g = 0; g < a.d; ++g) {
-            u64 f = (u64)x_freq<P>(x, g, j);
-            if (f) { ids[o] = g; freqs[o] = f; ++o; }
+__global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order,
+                                                         const u16* __restrict__ order16, const u64* __restrict__ candbits,
+                                                         const u64* __restrict__ wscan, u32* __restrict__ cand_node, u32* __restrict__ cand_poff,
+                                                         u32* __restrict__ ids, u64* __restrict__ freqs) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    for (u32 w = w0; w < nw; w += stride) {  // few nodes are candidates: most waves only look at their word
+        const u64 bits = candbits[w];
+        if (!bits) continue;
+        const u64 base = wscan[w];
+        const bool mine = (bits >> lane) & 1;
+        const u32 v = w * 64 + lane;
+        const u32 cnt = mine ? (a.d > 1 ? (u32)nT[v] : 1u) : 0u;  // pairs of this lane's candidate = samples that hold the node
+        const u32 k = (u32)(base & 0xFFFFFFFFu) + bits_below_lane(bits);
+        u32 o = k;
+        if (a.d > 1) o = (u32)(base >> 32) + (wave_inclusive_scan<u32>(cnt) - cnt);  // pairs of the candidates in lower lanes
+        if (!mine) continue;
+        cand_node[k] = v;
+        cand_poff[k] = o;
+        const u64 j = v;
+        if (a.exact_order == 1) {
+            const u64 ord = order[v];
+            for (u32 q = 0; q < cnt; ++q) {
+                u32 g = (u32)((ord >> (4 * q)) & 15);
+                ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
+            }
+        } else if (a.exact_order == 2) {
+            const u16* ord = order16 + (size_t)v * a.d;
+            for (u32 q = 0; q < cnt; ++q) {
+                u32 g = ord[q];
+                ids[o] = g; freqs[o] = (u64)x_freq<P>(x, g, j); ++o;
+            }
+        } else {
+            for (u32 g = 0; g < a.d; ++g) {
+                u64 f = (u64)x_freq<P>(x, g, j);
+                if (f) { ids[o] = g; freqs[o] = f; ++o; }
+            }
         }
     }
-    }  // flags
 }
 
 // stream mode (one sample): frequency and left char of every node of the level are retained for the wire stream
@@ -910,6 +998,29 @@ __global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__
         if (w >= nw) break;
         const u32 v = w * 64 + lane;
         T s = v < F ? (own ? (T)own[v] : (T)1) : (T)0;
+        if (child_agg) {
+            KidWave kw;
+            kid_wave(kids, w, kw);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((kw.p[c] >> lane) & 1) s += child_agg[kw.c[c] + bits_below_lane(kw.p[c])];
+        }
+        if (v < F) agg[v] = s;
+    }
+}
+// the same with own[v] = bit v of a word array (null: 0 everywhere): candidates in the subtree
+template <typename T>
+__global__ __launch_bounds__(256) void up_bits_kernel(u32 F, const u64* __restrict__ ownbits, Kids kids, const T* __restrict__ child_agg,
+                                                      T* __restrict__ agg) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride;
+        if (w >= nw) break;
+        const u32 v = w * 64 + lane;
+        T s = ownbits ? (T)((ownbits[w] >> lane) & 1) : (T)0;
         if (child_agg) {
             KidWave kw;
             kid_wave(kids, w, kw);
@@ -1080,7 +1191,7 @@ struct LevelHost {
     u32* kcum = nullptr;
     Kids kids() const { Kids k; k.plane = kplane; k.cum = kcum; return k; }
     // mine
-    u8* cand_flag = nullptr;
+    u64* cand_bits = nullptr;   // bit j of word w: node 64w + j is a candidate (one word per wave of 64 nodes)
     u32 ncand = 0, npairs = 0;
     u32* cand_node = nullptr;
     u32* cand_poff = nullptr;
@@ -1499,7 +1610,7 @@ class Engine {
     u8* samechild = nullptr;
     u64* order[2] = {nullptr, nullptr};
     u16* order16[2] = {nullptr, nullptr};  // d > 13
-    u64 *cand_key = nullptr, *cand_keyscan = nullptr, *scan_tmp64 = nullptr;
+    u64 *cand_wsum = nullptr, *cand_wscan = nullptr, *scan_tmp64 = nullptr;  // per wave of 64 nodes: candidates | pairs << 32, and their scan
     u64* d_counters = nullptr;
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
@@ -1678,9 +1789,9 @@ class Engine {
             for (int k = 0; k < 2; ++k)
                 if (int rc = dalloc(order16[k], (size_t)Fcap * d)) return rc;
         if (int rc = dalloc(samechild, Fcap)) return rc;
-        if (int rc = dalloc(cand_key, Fcap)) return rc;
-        if (int rc = dalloc(cand_keyscan, Fcap)) return rc;
-        if (int rc = dalloc(scan_tmp64, scan_tmp_elems(Fcap) + 8)) return rc;
+        if (int rc = dalloc(cand_wsum, nwave + 8)) return rc;
+        if (int rc = dalloc(cand_wscan, nwave + 8)) return rc;
+        if (int rc = dalloc(scan_tmp64, scan_tmp_elems(nwave) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
@@ -1963,8 +2074,9 @@ class Engine {
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
             ao.seg = Seg;
-            ao.h_totals = d_pub_tot; ao.h_childmax = d_pub_cmax; ao.d_total = d_totals;
+            ao.h_totals = d_pub_tot;
             ao.rp = d_rp_tab[nxt];
+            ao.rp0 = rp[nxt][0];
             ao.tpos = trie_mode ? d_tpos_tab : nullptr;
             ao.splane = d_splane_tab;
             ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp;
@@ -1981,7 +2093,8 @@ class Engine {
                 exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
                 if (!merged) ao.cnt_clear = cntraw;
             }
-            hipLaunchKernelGGL((advance_down_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
+            if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
+            else hipLaunchKernelGGL((advance_wave_kernel<P>), grid_npt(F), dim3(256), 0, st, x, ao);
             // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
@@ -1989,10 +2102,10 @@ class Engine {
             {
                 PublishArgs pa;
                 memset(&pa, 0, sizeof pa);
-                pa.src[0] = d_pub_tot; pa.dst[0] = h_totals; pa.words[0] = 1;
-                pa.src[2] = reinterpret_cast<const u32*>(d_pub_cmax); pa.dst[2] = reinterpret_cast<u32*>(h_childmax); pa.words[2] = 2u * (u32)world;
+                pa.src[0] = nbp == 1 ? d_pub_tot : d_totals; pa.dst[0] = h_totals; pa.words[0] = 1;  // new level's width: from the single tile, or the scan's total
+                pa.cmax_base = x.base; pa.cmax_bpr = x.bpr; pa.cmax_dst = h_childmax; pa.cmax_world = (u32)world;
                 if (filtered) {
-                    pa.src[3] = d == 1 ? d_totals + 2 : reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = d == 1 ? 1u : 2u;
+                    pa.src[3] = reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = 2u;
                 }
                 pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 pa.flag = h_totals + 310; pa.seq = ++pub_seq;
@@ -2140,30 +2253,21 @@ class Engine {
         return fa;
     }
     int emit_alloc(LevelHost& me, u32 F) {  // before the provisional window of the next level is taken from the arena
-        EARENA_GET(me.cand_flag, u8, F);
+        EARENA_GET(me.cand_bits, u64, ((size_t)F + 63) / 64);
         return 0;
     }
     int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
         const FilterArgs fa = filter_args(F, depth, order_mode);
-        const bool one = d == 1;
-        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild,
-                           me.cand_flag, one ? (u64*)nullptr : cand_key);
-        u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
-        if (one) {
-            exclusive_scan<u8, u32>(me.cand_flag, idx32, F, reinterpret_cast<u32*>(scan_tmp64), d_totals + 2, st);
-        } else {
-            exclusive_scan<u64, u64>(cand_key, cand_keyscan, F, scan_tmp64, d_totals64, st);
-        }
+        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild, me.cand_bits, cand_wsum);
+        exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
         return 0;
     }
     int emit_store(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {  // after the level's synchronisation
         const FilterArgs fa = filter_args(F, depth, order_mode);
-        const bool one = d == 1;
-        u32* idx32 = reinterpret_cast<u32*>(cand_keyscan);
         u64 tot = 0;
         memcpy(&tot, h_totals + 300, sizeof tot);
         me.ncand = (u32)(tot & 0xFFFFFFFFu);
-        me.npairs = one ? me.ncand : (u32)(tot >> 32);
+        me.npairs = (u32)(tot >> 32);
         if (me.ncand) {
             u32 nc = me.ncand;
             me.ncand = 0;  // stays 0 if the store does not fit: the level then has no usable candidates
@@ -2172,8 +2276,8 @@ class Engine {
             EARENA_GET(me.ids, u32, me.npairs);
             EARENA_GET(me.freqs, u64, me.npairs);
             me.ncand = nc;
-            hipLaunchKernelGGL((cand_store_kernel<P>), grid_for(((u64)F + 7) / 8), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_flag,
-                               one ? (const u64*)nullptr : cand_keyscan, idx32, me.cand_node, me.cand_poff, me.ids, me.freqs);
+            hipLaunchKernelGGL((cand_store_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_bits, cand_wscan,
+                               me.cand_node, me.cand_poff, me.ids, me.freqs);
         }
         stats.candidates += me.ncand;
         return 0;
@@ -2191,11 +2295,8 @@ class Engine {
         for (u32 l = nlev; l-- > 1;) {
             EARENA_GET(L[l].sub, u32, L[l].n);
             const u32* child_sub = l + 1 < nlev ? L[l + 1].sub : nullptr;
-            if (!L[l].cand_flag) {  // level outside the emitted depth range: no candidates of its own
-                EARENA_GET(L[l].cand_flag, u8, L[l].n);
-                DSM_HIP(hipMemsetAsync(L[l].cand_flag, 0, L[l].n, st));
-            }
-            hipLaunchKernelGGL((up_kernel<u32, u8>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_flag, L[l].kids(), child_sub, L[l].sub);
+            // (a level outside the emitted depth range has no candidates of its own: no word array)
+            hipLaunchKernelGGL((up_bits_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].cand_bits, L[l].kids(), child_sub, L[l].sub);
         }
         // top-down: start offsets (two rolling arrays); every candidate's post-order rank, and its sizes at that rank
         u32 *plen, *npair;
