@@ -39,19 +39,7 @@ namespace dsm {
 // ---------------------------------------------------------------------------------------------
 // rank on the bit-plane blocks
 // ---------------------------------------------------------------------------------------------
-struct RankCache {
-    u64 bi;   // block currently held in r
-    Blk16 r;
-};
-
-__device__ __forceinline__ void rc_select(const DevIndex& ix, RankCache& rc, u64 x, u32& lines) {
-    u64 bi = x >> BLK_SHIFT;
-    if (bi != rc.bi) {
-        load_blk(ix.blk, bi, rc.r);
-        ++lines;
-        rc.bi = bi;
-    }
-}
+#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
 
 // occurrences of A,C,G,T among the first `off` symbols of a block with four population counts:
 // |base|, |base & p1| = G+T, |base & p0| = C+T, |base & p1 & p0| = T
@@ -68,45 +56,62 @@ __device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4])
 }
 
 // Superblock bases (C[c] + occurrences of c before the superblock).  An index below 2^31 symbols has one superblock:
-// its four bases travel as kernel arguments (scalar registers) instead of a dependent vector load per rank.  The choice is
-// a template parameter (ONESB), not a run-time select: selecting between the argument block and the device array turns
-// every access into a flat load, whose wait also drains every prefetch in flight.
+// its four bases travel as kernel arguments (scalar registers).  Larger indexes keep the table in LDS (sbl): a read of it
+// is an LDS access, which does not queue behind the global prefetches the way a global load would.  The choice is a template
+// parameter (ONESB), not a run-time select: selecting between the argument block and memory turns every access into a flat
+// load, whose wait also drains every prefetch in flight.
 struct SbArgs {
     u64 sb0[4];
 };
+constexpr u32 SB_LDS_MAX = 64;  // superblocks the LDS copy holds (2^37 symbols)
 
 // LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
 template <typename P, bool ONESB>
-__device__ __forceinline__ void rank4_blk(const DevIndex& ix, const SbArgs& sa, const Blk16& r, u64 x, P out[4]) {
+__device__ __forceinline__ void rank4_blk(const SbArgs& sa, const u64* sbl, const Blk16& r, u64 x, P out[4]) {
     u32 c4[4];
     blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
-    if (ONESB) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out[c] = (P)(sa.sb0[c] + r.cnt[c] + c4[c]);
-    } else {
-        const u64* sb = ix.sbase + (x >> SB_SHIFT) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) out[c] = (P)(sb[c] + r.cnt[c] + c4[c]);
-    }
+    for (int c = 0; c < 4; ++c) out[c] = (P)((ONESB ? sa.sb0[c] : sbl[(x >> SB_SHIFT) * 4 + c]) + r.cnt[c] + c4[c]);
 }
 
-// the same for the bases selected by `want` only (the children that survive): one masked popcount per base
+// LF(c, x-1) for one base chosen per lane (c = 0..3), on the plane words of a block; cntc = the block's count of that base.
+// A plane is taken as it is or inverted, so the base needs no branch.
 template <typename P, bool ONESB>
-__device__ __forceinline__ void rank_sel(const DevIndex& ix, const SbArgs& sa, RankCache& rc, u64 x, u32 want, P out[4], u32& lines) {
-    rc_select(ix, rc, x, lines);
-    const Blk16& r = rc.r;
+__device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a, u64 p0b, u64 p1a, u64 p1b, u64 p2a, u64 p2b, u32 cntc, u64 x, u32 c) {
     const u32 off = (u32)(x & (BLK_SYMS - 1));
-    u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
-    u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
-    u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (!((want >> c) & 1u)) continue;
-        u64 xa = ba & ((c & 2) ? r.p1a : ~r.p1a) & ((c & 1) ? r.p0a : ~r.p0a);
-        u64 xb = bb & ((c & 2) ? r.p1b : ~r.p1b) & ((c & 1) ? r.p0b : ~r.p0b);
-        const u64 base = ONESB ? sa.sb0[c] : ix.sbase[(x >> SB_SHIFT) * 4 + c];
-        out[c] = (P)(base + r.cnt[c] + (u32)(__popcll(xa) + __popcll(xb)));
-    }
+    const u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
+    const u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+    const u64 i0 = (c & 1u) ? 0ull : ~0ull, i1 = (c & 2u) ? 0ull : ~0ull;
+    const u64 xa = ma & ~p2a & (p1a ^ i1) & (p0a ^ i0);
+    const u64 xb = mb & ~p2b & (p1b ^ i1) & (p0b ^ i0);
+    const u64 base = ONESB ? DSM_PICK(sa.sb0, c) : sbl[(x >> SB_SHIFT) * 4 + c];
+    return (P)(base + cntc + (u32)(__popcll(xa) + __popcll(xb)));
+}
+
+// The two index blocks of a lane (block of sp, block of ep + 1) are parked in LDS once its four-base ranks are done: the
+// left-extension ranks that follow read the words they need from there (an LDS access neither holds registers in between nor
+// queues behind the global prefetches).  Layout per wave: [block 0/1][16-byte quarter][lane], so the lanes of a read touch
+// consecutive 16-byte words (no bank conflicts).  A lane only ever reads what it wrote itself.
+constexpr u32 WAVE_LDS_WORDS = 2 * 4 * 64;  // uint4 per wave (8 KB)
+__device__ __forceinline__ void park_blk(uint4* wl, u32 which, int lane, const Blk16& b) {
+    wl[(which * 4 + 0) * 64 + lane] = make_uint4(b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3]);
+    wl[(which * 4 + 1) * 64 + lane] = make_uint4((u32)b.p0a, (u32)(b.p0a >> 32), (u32)b.p0b, (u32)(b.p0b >> 32));
+    wl[(which * 4 + 2) * 64 + lane] = make_uint4((u32)b.p1a, (u32)(b.p1a >> 32), (u32)b.p1b, (u32)(b.p1b >> 32));
+    wl[(which * 4 + 3) * 64 + lane] = make_uint4((u32)b.p2a, (u32)(b.p2a >> 32), (u32)b.p2b, (u32)(b.p2b >> 32));
+}
+template <typename P, bool ONESB>
+__device__ __forceinline__ P rank_parked(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 which, int lane, u64 x, u32 c) {
+    const uint4 q1 = wl[(which * 4 + 1) * 64 + lane], q2 = wl[(which * 4 + 2) * 64 + lane], q3 = wl[(which * 4 + 3) * 64 + lane];
+    const u32 cntc = reinterpret_cast<const u32*>(wl + (which * 4 + 0) * 64 + lane)[c];
+    return rank_one<P, ONESB>(sa, sbl, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z, ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z,
+                              ((u64)q3.y << 32) | q3.x, ((u64)q3.w << 32) | q3.z, cntc, x, c);
+}
+// the same from memory (positions outside the two blocks a lane holds: intervals over more than two blocks only)
+template <typename P, bool ONESB>
+__device__ __forceinline__ P rank_load(const DevIndex& ix, const SbArgs& sa, const u64* sbl, u64 x, u32 c) {
+    Blk16 b;
+    load_blk(ix.blk, x >> BLK_SHIFT, b);
+    return rank_one<P, ONESB>(sa, sbl, b.p0a, b.p0b, b.p1a, b.p1b, b.p2a, b.p2b, DSM_PICK(b.cnt, c), x, c);
 }
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -115,12 +120,18 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     return v;
 }
 
-// record layout (struct of arrays): field f of record r lives at rec[f * cap + r]
-//   0 sp  1 ep  2..5 min of the non-empty left-extension intervals  6..9 their max   (EnumerateQuery.h:44-45, Query.h:110-111)
-// followed by one byte per record: bit a set = the ext interval of base a (A,C,G,T) is non-empty.  Only the non-empty
-// intervals are stored, in base order, in the first popcount(mask) slots: most nodes have one, so the other slots are
-// neither written nor read.  Records are addressed through a handle per frontier node (rp[v]); DEAD = the node is
-// absent from this sample.
+// Records (EnumerateQuery.h:44-45, Query.h:110-111): the interval [sp, ep] of a node in the sample and its non-empty
+// left-extension intervals, kept in base order in the first popcount(mask) of four slots (mask bit a: the interval of base a
+// is non-empty).  Records are addressed through a handle per frontier node (rp[v]); DEAD = the node is absent from this sample.
+// Two formats, chosen per level:
+//   wide (struct of arrays)  field f of record r lives at rec[f * cap + r]: 0 sp, 1 ep, 2 + 2e / 3 + 2e = min / max of slot e,
+//                            followed by one mask byte per record.  Used while frequencies may reach 65535 (the top few levels
+//                            of a prefix) and, in every level, for slots 2 and 3 (fewer than one node in a hundred has them).
+//   compact                  one 16-byte word per record (32 bytes with 64-bit positions): sp, then 16-bit ep - sp and the
+//                            offsets from sp of the ends of slots 0 and 1, then the mask.  A level is compact when every frequency
+//                            of its parent level is below 65535.  One load / one store per record instead of seven: the LF-step
+//                            kernel is bound by the memory transactions it issues, not by their bytes.  The words share the
+//                            memory of fields 0-3 of the wide format (a level has one format).
 //
 // Order of a level.  The nodes of a level are kept in COLEX order of their paths (sorted by the reversed substring), not in
 // trie order.  The index holds reversed reads, so the suffix-array interval of a substring P is ordered by reverse(P):
@@ -195,8 +206,6 @@ template <typename P> struct Vec4;
 template <> struct Vec4<u32> { typedef uint4 type; };
 template <> struct Vec4<u64> { typedef ulonglong4 type; };
 
-#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
-
 // The LF-step kernel.  A wave owns tiles of 64 consecutive nodes of the (colex-ordered) union level and walks them with a
 // grid stride; the waves of a launch are all resident, so the launch sweeps the level -- and with it the sample's records
 // and the index -- front to back.  While a tile is being ranked, the record heads of the wave's next tile and the handles
@@ -206,22 +215,95 @@ template <> struct Vec4<u64> { typedef ulonglong4 type; };
 // splane receives, per tile, the four bit planes "this sample keeps child c of node j" (the advance kernel derives the
 // children's record handles from them); cnt (single sample only: the union trie is the sample's trie) accumulates the child
 // counts per symbol and 256-node tile for the scan.
+constexpr u32 CREC_WORDS(size_t psize) { return psize == 4 ? 1u : 2u; }  // uint4 per compact record
+
+template <typename P, bool INC>
+struct RecHead;
 template <typename P>
-struct RecHead {   // what a lane needs of its record before anything can be ranked
-    P sp, ep, e0min, e0max;
+struct RecHead<P, false> {   // what a lane needs of its record before anything can be ranked (wide format: decoded fields)
+    P sp, ep, e0min, e0max, e1min, e1max;
     u32 flags;     // bits 0-3: mask of the non-empty left-extension intervals, bit 8: the node is present in this sample
+    u32 r;         // the record's handle (the few nodes with more than two intervals read the others through it)
 };
-// Every load of the pipeline is unconditional (absent nodes read record 0 and discard it): a load behind a branch would make
-// the compiler wait for ALL outstanding loads at the join, and the prefetches would stop being prefetches.
 template <typename P>
-__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P>& h) {
+struct RecHead<P, true> {    // compact format: the raw words, decoded when the tile is worked on
+    uint4 w[sizeof(P) == 4 ? 1 : 2];
+    u32 r;         // handle, DEAD for an absent node
+};
+// Every load of the pipeline is unconditional (absent nodes read record 0 and discard it; the first two interval slots are
+// read whether or not they are in use): a load behind a branch makes the compiler wait for ALL outstanding loads at the join --
+// the prefetches would stop being prefetches -- and one node in ten has two intervals, i.e. nearly every wave has such a lane.
+template <typename P>
+__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, false>& h) {
     const bool live = r != DEAD;
     const u32 rr = live ? r : 0u;
     const P sp = rec[rr], ep = rec[cap + rr];
-    const P e0 = rec[2 * cap + rr], e1 = rec[6 * cap + rr];   // slot 0 is read whether or not it is in use: no load depends on the mask byte
+    h.e0min = rec[2 * cap + rr]; h.e0max = rec[3 * cap + rr];
+    h.e1min = rec[4 * cap + rr]; h.e1max = rec[5 * cap + rr];
     const u32 m = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * cap)[rr];
-    h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0; h.e0min = e0; h.e0max = e1;
+    h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0;
     h.flags = live ? (m | 0x100u) : 0u;
+    h.r = rr;
+}
+template <typename P>
+__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, true>& h) {
+    const uint4* c = reinterpret_cast<const uint4*>(rec) + (size_t)(r != DEAD ? r : 0u) * CREC_WORDS(sizeof(P));
+    h.w[0] = c[0];
+    if (sizeof(P) == 8) h.w[sizeof(P) == 4 ? 0 : 1] = c[sizeof(P) == 4 ? 0 : 1];
+    h.r = r;
+}
+// decoded view of a head
+template <typename P>
+struct NodeIn {
+    P sp, ep, e0min, e0max, e1min, e1max;
+    u32 emask, r;
+    bool live;
+};
+template <typename P>
+__device__ __forceinline__ void decode_head(const RecHead<P, false>& h, NodeIn<P>& n) {
+    n.sp = h.sp; n.ep = h.ep; n.e0min = h.e0min; n.e0max = h.e0max; n.e1min = h.e1min; n.e1max = h.e1max;
+    n.emask = h.flags & 15u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
+}
+__device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<u32>& n) {
+    const uint4 v = h.w[0];
+    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
+    const u32 sp = v.x;
+    n.sp = n.live ? sp : 1u;
+    n.ep = n.live ? sp + (v.y & 0xFFFFu) : 0u;
+    n.e0min = sp + (v.y >> 16); n.e0max = sp + (v.z & 0xFFFFu);
+    n.e1min = sp + (v.z >> 16); n.e1max = sp + (v.w & 0xFFFFu);
+    n.emask = n.live ? (v.w >> 16) & 15u : 0u;
+}
+__device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<u64>& n) {
+    const uint4 v = h.w[0], x = h.w[1];
+    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
+    const u64 sp = ((u64)v.y << 32) | v.x;
+    n.sp = n.live ? sp : 1ull;
+    n.ep = n.live ? sp + (v.z & 0xFFFFu) : 0ull;
+    n.e0min = sp + (v.z >> 16); n.e0max = sp + (v.w & 0xFFFFu);
+    n.e1min = sp + (v.w >> 16); n.e1max = sp + (x.x & 0xFFFFu);
+    n.emask = n.live ? (x.x >> 16) & 15u : 0u;
+}
+// A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions (slots 2, 3 went to the wide fields already)
+template <typename P, bool OUTC>
+__device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32 q, P nsp, P nep, P l0, P h0, P l1, P h1, u32 cn, u32 cm) {
+    if (OUTC) {
+        uint4* c = reinterpret_cast<uint4*>(out) + (size_t)q * CREC_WORDS(sizeof(P));
+        const u32 len = (u32)(nep - nsp), a0 = cn > 0 ? (u32)(l0 - nsp) : 0u, b0 = cn > 0 ? (u32)(h0 - nsp) : 0u,
+                  a1 = cn > 1 ? (u32)(l1 - nsp) : 0u, b1 = cn > 1 ? (u32)(h1 - nsp) : 0u;
+        if (sizeof(P) == 4) {
+            c[0] = make_uint4((u32)nsp, len | (a0 << 16), b0 | (a1 << 16), b1 | (cm << 16));
+        } else {
+            c[0] = make_uint4((u32)nsp, (u32)((u64)nsp >> 32), len | (a0 << 16), b0 | (a1 << 16));
+            c[sizeof(P) == 4 ? 0 : 1] = make_uint4(b1 | (cm << 16), 0u, 0u, 0u);
+        }
+    } else {
+        out[q] = nsp;
+        out[cap + q] = nep;
+        if (cn > 0) { out[2 * cap + q] = l0; out[3 * cap + q] = h0; }
+        if (cn > 1) { out[4 * cap + q] = l1; out[5 * cap + q] = h1; }
+        reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[q] = (u8)cm;
+    }
 }
 
 struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
@@ -232,56 +314,47 @@ struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
 
 // One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
 // whose handles are in rn (requested one tile ago); rn then receives the handles of the tile after that.
-template <typename P, bool ONESB>
-__device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                            u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf, u8* __restrict__ pl,
-                                            const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile, const RecHead<P>& hc,
-                                            RecHead<P>& hn, u32& rn, ExpandAcc& acc) {
+template <typename P, bool ONESB, bool INC, bool OUTC>
+__device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, uint4* wl, const u32* __restrict__ rp, const P* __restrict__ rec,
+                                            P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
+                                            u8* __restrict__ pl, const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile,
+                                            const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
     const size_t cap = a.cap;
     const u32 i = t * 64 + lane;
-    const bool live = (hc.flags & 0x100u) != 0;
-    const P sp = hc.sp, ep = hc.ep;
-    const u32 emask = hc.flags & 15u;
+    NodeIn<P> nd;
+    decode_head(hc, nd);
+    const bool live = nd.live;
+    const P sp = nd.sp, ep = nd.ep;
+    const u32 emask = nd.emask;
     const u32 ne = __popc(emask);
     // both ends of the interval are requested before anything waits (absent nodes: sp = 1, ep = 0 -> block 0, twice)
-    RankCache rc;
-    Blk16 r1;          // block of ep + 1
-    rc.bi = (u64)sp >> BLK_SHIFT;
-    const u64 b1 = ((u64)ep + 1) >> BLK_SHIFT;
-    load_blk(ix.blk, rc.bi, rc.r);
-    load_blk(ix.blk, b1, r1);
-    // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for the
-    // blocks leaves them in flight) ----
-    load_head<P>(rec, cap, rn, hn);
-    {
-        const u32 t2 = t + 2 * nwaves;
-        const u32 i2 = t2 * 64 + lane;
-        const bool in2 = t2 < ntile && i2 < a.F;
-        const u32 v = rp[in2 ? i2 : 0u];
-        rn = in2 ? v : DEAD;
-    }
-
+    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;
     u32 n_lf = 0, n_rank = 0, lines = 0;
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
-    u32 mycode = 0;   // left-char code of this node itself (EnumerateQuery::leftChar on its own record)
-    u32 r = DEAD;     // this node's record handle: only the rare nodes with several left-extension intervals need it again
-    {   // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty,
-        // and straight-line code keeps the compiler from sinking the block loads behind the prefetches.
-        bool matches = ne > 0 && hc.e0min == sp && hc.e0max == ep;
-        if (ne > 1) {  // rare: more than one left-extension interval (read again by the ext pass: they are not kept in registers)
-            r = rp[i];
-#pragma unroll
-            for (int e = 1; e < 4; ++e)
-                if ((u32)e < ne && rec[(size_t)(2 + e) * cap + r] == sp && rec[(size_t)(6 + e) * cap + r] == ep) matches = true;
+    {
+        Blk16 r0, r1;      // blocks of sp and of ep + 1
+        load_blk(ix.blk, b0, r0);
+        load_blk(ix.blk, b1, r1);
+        // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
+        // the blocks leaves them in flight) ----
+        load_head<P>(rec, cap, rn, hn);
+        {
+            const u32 t2 = t + 2 * nwaves;
+            const u32 i2 = t2 * 64 + lane;
+            const bool in2 = t2 < ntile && i2 < a.F;
+            const u32 v = rp[in2 ? i2 : 0u];
+            rn = in2 ? v : DEAD;
         }
-        // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
-        mycode = matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u);
-        rank4_blk<P, ONESB>(ix, a.sb, rc.r, (u64)sp, Rsp);  // LF(c, sp-1)
-        const u32 lcode = blk_code_at(rc.r, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-        rank4_blk<P, ONESB>(ix, a.sb, r1, (u64)ep + 1, Rep);  // LF(c, ep); rc keeps the first block for the ext pass
+        // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty,
+        // and straight-line code keeps the compiler from sinking the block loads behind the prefetches.
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)sp, Rsp);  // LF(c, sp-1)
+        const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
+        rank4_blk<P, ONESB>(a.sb, sbl, r1, (u64)ep + 1, Rep);  // LF(c, ep)
+        park_blk(wl, 0, lane, r0);
+        park_blk(wl, 1, lane, r1);
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         if (single && a.allowed) n_rank += (a.access_pack >> (4 * lcode)) & 15u;
 #pragma unroll
@@ -299,8 +372,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __res
                 }
             }
         }
-        if (!live) { n_lf = 0; n_rank = 0; present = 0; mycode = 0; }
+        if (!live) { n_lf = 0; n_rank = 0; present = 0; }
     }
+    asm volatile("" ::: "memory");  // what follows reads the blocks from LDS, not from registers kept alive across the rounds
     {   // index lines this wave asks for at the interval ends: intervals are disjoint and increasing along the lanes, so a
         // block is new to the wave iff it lies beyond every block of the lower lanes (lanes that share a block share the line)
         const u32 bend = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane
@@ -309,7 +383,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __res
         for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
         u32 prev = __shfl_up(pm, 1, 64);
         if (lane == 0) prev = 0;
-        if (live) lines += ((u32)rc.bi + 1u > prev ? 1u : 0u) + ((b1 != rc.bi && (u32)b1 + 1u > prev) ? 1u : 0u);
+        if (live) lines += ((u32)b0 + 1u > prev ? 1u : 0u) + ((b1 != b0 && (u32)b1 + 1u > prev) ? 1u : 0u);
     }
     // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
     const u32 k = __popc(present);
@@ -326,82 +400,80 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __res
         const u32 nb = (u32)__popcll(b);
         if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
     }
-    if (i < a.F) {
-        // Child records are written child-slot by child-slot (slot j = the j-th surviving base of the lane), not base by base:
-        // most nodes have one child, so a wave usually runs one pass over the fields instead of four; the lanes of a pass that
-        // write the same symbol write neighbouring handles.  cj[j] = base of slot j, qj[j] = its handle.
-        u32 cj[4], qj[4];
-        {
-            u32 m = present;
+    // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
+    bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
+    if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
+        if (ne > 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cj[j] = m ? (u32)__ffs(m) - 1u : 0u; m &= m - 1; qj[j] = DSM_PICK(qa, cj[j]); }
+            for (int e = 2; e < 4; ++e)
+                if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * cap + nd.r] == sp && rec[(size_t)(3 + 2 * e) * cap + nd.r] == ep) matches = true;
         }
-        const u32 kmax = __any(k > 0) ? (__any(k > 3) ? 4u : (__any(k > 2) ? 3u : (__any(k > 1) ? 2u : 1u))) : 0u;
+    }
+    // ---- child records.  A lane's work is the list of its (child, left-extension interval) pairs, child-major: most lanes have
+    // one pair, one in ten has two, so a wave runs about two rounds instead of (most children) x (most intervals).  Per pair: LF
+    // with the child's base at both ends of the parent's interval (EnumerateQuery.cpp:44-55) -- an end that coincides with sp or
+    // ep + 1 is the child's own end -- and the child keeps the interval if it stays non-empty, compacted into its first slots.
+    // The ends lie inside [sp, ep + 1], i.e. in one of the two parked blocks unless the interval spans more than two blocks.
+    {
+        const u32 ne1 = ne ? ne : 1u;
+        const u32 npair = k * ne1;
+        u32 cjpack = 0, kkpack = 0;  // two bits per slot: bases of the children / of the intervals, in order
+        {
+            u32 m = present, mm = emask;
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            if (j < kmax && j < k) {
-                const u32 c = cj[j], q = qj[j];
-                out[q] = DSM_PICK(Rsp, c);
-                out[cap + q] = DSM_PICK(Rep, c) - 1;
+            for (int q = 0; q < 4; ++q) {
+                cjpack |= (m ? (u32)__ffs(m) - 1u : 0u) << (2 * q); m &= m - 1;
+                kkpack |= (mm ? (u32)__ffs(mm) - 1u : 0u) << (2 * q); mm &= mm - 1;
             }
         }
-        if (present) {
-            // left-extension intervals of the children (EnumerateQuery.cpp:44-55): LF at both ends of every non-empty
-            // parent ext, only for the bases that survive.  Ends that coincide with sp / ep+1 or with the previous
-            // position (adjacent ext intervals share them) are not evaluated again.  A child keeps the intervals that stay
-            // non-empty, compacted into its first slots.
-            u64 lastx = ~0ull;
-            P lastv[4] = {0, 0, 0, 0};
-            u32 cm[4] = {0, 0, 0, 0};   // mask of child slot j
-            u32 cn[4] = {0, 0, 0, 0};   // its number of stored intervals
-            u32 mm = emask;
-            const u32 nemax = __any(mm & (mm - 1)) ? 4u : 1u;  // some lane holds more than one interval?
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if ((u32)e < nemax && mm) {
-                    const u32 kk = (u32)__ffs(mm) - 1u;
-                    mm &= mm - 1;
-                    P lo[4] = {1, 1, 1, 1}, hi[4] = {1, 1, 1, 1};
-                    const u64 xl = e == 0 ? (u64)hc.e0min : (u64)rec[(size_t)(2 + e) * cap + r];
-                    const u64 xh = (e == 0 ? (u64)hc.e0max : (u64)rec[(size_t)(6 + e) * cap + r]) + 1;
-                    if (xl == (u64)sp) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) lo[c] = Rsp[c];
-                    } else if (xl == lastx) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) lo[c] = lastv[c];
-                    } else {
-                        rank_sel<P, ONESB>(ix, a.sb, rc, xl, present, lo, lines);
-                    }
-                    if (xh == (u64)ep + 1) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) hi[c] = Rep[c];
-                    } else {
-                        rank_sel<P, ONESB>(ix, a.sb, rc, xh, present, hi, lines);
-                        lastx = xh;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) lastv[c] = hi[c];
-                    }
-#pragma unroll
-                    for (u32 j = 0; j < 4; ++j) {
-                        if (j < kmax && j < k) {
-                            const u32 c = cj[j], q = qj[j];
-                            const P l = DSM_PICK(lo, c), h = DSM_PICK(hi, c);
-                            if (l <= h - 1) {
-                                out[(size_t)(2 + cn[j]) * cap + q] = l;
-                                out[(size_t)(6 + cn[j]) * cap + q] = h - 1;
-                                ++cn[j];
-                                cm[j] |= 1u << kk;
-                            }
-                        }
-                    }
+        u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
+        P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
+#pragma nounroll
+        for (u32 p = 0; __any(p < npair); ++p) {
+            const bool act = p < npair;
+            const u32 j = ne1 == 1 ? p : (ne1 == 2 ? p >> 1 : (ne1 == 4 ? p >> 2 : (p * 11u) >> 5));  // p / ne1 for p < 16
+            const u32 e = p - j * ne1;
+            const u32 c = (cjpack >> (2 * j)) & 3u, kk = (kkpack >> (2 * e)) & 3u;
+            const u32 q = DSM_PICK(qa, c);
+            const P nsp = DSM_PICK(Rsp, c), nep1 = DSM_PICK(Rep, c);  // the child's interval is [nsp, nep1 - 1]
+            if (e == 0) { cn = 0; cm = 0; }
+            const bool hasext = act && ne > 0;
+            P xmin = e == 0 ? nd.e0min : nd.e1min, xmax = e == 0 ? nd.e0max : nd.e1max;
+            if (__any(hasext && e > 1)) {
+                if (hasext && e > 1) {
+                    xmin = rec[(size_t)(2 + 2 * e) * cap + nd.r];
+                    xmax = rec[(size_t)(3 + 2 * e) * cap + nd.r];
                 }
             }
-            u8* omask = reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap);
-#pragma unroll
-            for (u32 j = 0; j < 4; ++j)
-                if (j < kmax && j < k) omask[qj[j]] = (u8)cm[j];
+            const u64 xl = hasext ? (u64)xmin : (u64)sp, xh = hasext ? (u64)xmax + 1 : (u64)ep + 1;
+            P l = nsp, h = nep1;
+            const bool needl = xl != (u64)sp, needh = xh != (u64)ep + 1;
+            if (__any(needl)) {
+                if (needl) {
+                    const u64 bl = xl >> BLK_SHIFT;
+                    if (bl == b0 || bl == b1) l = rank_parked<P, ONESB>(a.sb, sbl, wl, bl != b0 ? 1u : 0u, lane, xl, c);
+                    else { l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c); ++lines; }
+                }
+            }
+            if (__any(needh)) {
+                if (needh) {
+                    const u64 bh = xh >> BLK_SHIFT;
+                    if (bh == b0 || bh == b1) h = rank_parked<P, ONESB>(a.sb, sbl, wl, bh != b0 ? 1u : 0u, lane, xh, c);
+                    else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
+                }
+            }
+            if (hasext && l <= h - 1) {
+                if (cn == 0) { kl0 = l; kh0 = h - 1; }
+                else if (cn == 1) { kl1 = l; kh1 = h - 1; }
+                else { out[(size_t)(2 + 2 * cn) * cap + q] = l; out[(size_t)(3 + 2 * cn) * cap + q] = h - 1; }  // slots 2, 3: wide fields
+                ++cn;
+                cm |= 1u << kk;
+            }
+            if (act && e == ne1 - 1) store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
         }
+    }
+    const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
+    if (i < a.F) {
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
@@ -410,11 +482,19 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u32* __res
     acc.kne += k | (ne << 16); acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
 }
 
-template <typename P, bool ONESB>
+template <typename P, bool ONESB, bool INC, bool OUTC>
 __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
                                                      u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                                      u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
                                                      unsigned long long* __restrict__ childmax) {
+    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
+    __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
+    uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
+    if (!ONESB) {
+        const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
+        for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const u32 nwaves = gridDim.x * 4;
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -427,12 +507,13 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
         const u32 i0 = gw * 64 + lane, i1 = (gw + nwaves) * 64 + lane;
         if (gw < ntile && i0 < a.F) r0 = rp[i0];
         if (gw + nwaves < ntile && i1 < a.F) rn = rp[i1];
-        RecHead<P> hA, hB;
+        RecHead<P, INC> hA, hB;
         load_head<P>(rec, a.cap, r0, hA);
         // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
         for (u32 t = gw; t < ntile; t += 2 * nwaves) {
-            expand_tile<P, ONESB>(ix, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc);
-            if (t + nwaves < ntile) expand_tile<P, ONESB>(ix, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc);
+            expand_tile<P, ONESB, INC, OUTC>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc);
+            if (t + nwaves < ntile)
+                expand_tile<P, ONESB, INC, OUTC>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc);
         }
     }
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
@@ -1774,7 +1855,7 @@ class Engine {
         {   // all waves of an LF-step launch are resident: blocks = CUs x blocks per CU at the kernel's register footprint
             int cus = 0, per = 0;
             DSM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            DSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, expand_kernel<P, true>, 256, 0));
+            DSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (expand_kernel<P, true, true, true>), 256, 0));
             if (const char* e = getenv("DSM_EXPAND_BLOCKS_PER_CU")) per = atoi(e);
             if (per < 1) per = 1;
             expand_blocks = (u32)(cus > 0 ? cus : 256) * (u32)per;
@@ -1915,7 +1996,7 @@ class Engine {
             int slot = 0;
             for (int a = 0; a < 4; ++a) {
                 u64 lo = m.C[(int)bases[a]], cnt = m.codes[(int)bases[a]].count;  // LF(a,-1), LF(a,n-1)
-                if (cnt) { h[2 + slot] = (P)lo; h[6 + slot] = (P)(lo + cnt - 1); ++slot; hmask |= (u8)(1u << a); }
+                if (cnt) { h[2 + 2 * slot] = (P)lo; h[3 + 2 * slot] = (P)(lo + cnt - 1); ++slot; hmask |= (u8)(1u << a); }
             }
             for (int f = 0; f < REC_FIELDS; ++f)
                 DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Rcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
@@ -1960,6 +2041,7 @@ class Engine {
         // The expand launch of a level is queued as early as possible: for level L+1 right after the synchronisation of
         // level L, ahead of that level's remaining small launches (order, candidate store), so the GPU does not wait for
         // the host to get through them.
+        bool fmt_in = false;  // format of the records of the level about to be expanded (the root's record is wide)
         auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16) -> int {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
@@ -2014,16 +2096,24 @@ class Engine {
                 const u32 need = (F + TILE - 1) / TILE;
                 const dim3 eg(need < expand_blocks ? need : expand_blocks);
                 u32* ecnt = (d == 1 && ea.nbp > 1) ? cntraw : (u32*)nullptr;
-                if (one_sb)
-                    hipLaunchKernelGGL((expand_kernel<P, true>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, cf, cl,
-                                       ea, d_counters, d_childmax);
-                else
-                    hipLaunchKernelGGL((expand_kernel<P, false>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, cf, cl,
-                                       ea, d_counters, d_childmax);
+                // record formats: this level's records are compact iff its parent level was narrow (fmt_in), the children's iff this one is
+#define DSM_LAUNCH_EXPAND(SB, IC, OC)                                                                                               \
+    hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], \
+                       ecnt, cf, cl, ea, d_counters, d_childmax)
+                const bool oc = w16;
+                if (one_sb) {
+                    if (fmt_in) { if (oc) DSM_LAUNCH_EXPAND(true, true, true); else DSM_LAUNCH_EXPAND(true, true, false); }
+                    else { if (oc) DSM_LAUNCH_EXPAND(true, false, true); else DSM_LAUNCH_EXPAND(true, false, false); }
+                } else {
+                    if (fmt_in) { if (oc) DSM_LAUNCH_EXPAND(false, true, true); else DSM_LAUNCH_EXPAND(false, true, false); }
+                    else { if (oc) DSM_LAUNCH_EXPAND(false, false, true); else DSM_LAUNCH_EXPAND(false, false, false); }
+                }
+#undef DSM_LAUNCH_EXPAND
                 ++stats.expand_launches;
                 stats.expand_slots += F;
                 stats.expand_column_bytes += (u64)F * (fb + 1);
             }
+            fmt_in = w16 && !trie_mode;  // the next level's records
             DSM_HIP(hipEventRecord(ea1, st));
             if (device < 16) { g_expand_chain.last[device] = ea1; g_expand_chain.owner[device] = this; }
             chain_lock.unlock();
