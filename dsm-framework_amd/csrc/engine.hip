@@ -88,21 +88,26 @@ __device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a,
     return (P)(base + cntc + (u32)(__popcll(xa) + __popcll(xb)));
 }
 
-// The two index blocks of a lane (block of sp, block of ep + 1) are parked in LDS once its four-base ranks are done: the
-// left-extension ranks that follow read the words they need from there (an LDS access neither holds registers in between nor
-// queues behind the global prefetches).  Layout per wave: [block 0/1][16-byte quarter][lane], so the lanes of a read touch
-// consecutive 16-byte words (no bank conflicts).  A lane only ever reads what it wrote itself.
-constexpr u32 WAVE_LDS_WORDS = 2 * 4 * 64;  // uint4 per wave (8 KB)
-__device__ __forceinline__ void park_blk(uint4* wl, u32 which, int lane, const Blk16& b) {
-    wl[(which * 4 + 0) * 64 + lane] = make_uint4(b.cnt[0], b.cnt[1], b.cnt[2], b.cnt[3]);
-    wl[(which * 4 + 1) * 64 + lane] = make_uint4((u32)b.p0a, (u32)(b.p0a >> 32), (u32)b.p0b, (u32)(b.p0b >> 32));
-    wl[(which * 4 + 2) * 64 + lane] = make_uint4((u32)b.p1a, (u32)(b.p1a >> 32), (u32)b.p1b, (u32)(b.p1b >> 32));
-    wl[(which * 4 + 3) * 64 + lane] = make_uint4((u32)b.p2a, (u32)(b.p2a >> 32), (u32)b.p2b, (u32)(b.p2b >> 32));
+// The index blocks of a tile are staged in LDS.  The intervals of a tile's nodes are disjoint and increase along the lanes, so
+// the blocks the lanes need (block of sp, block of ep + 1) form a non-decreasing sequence: the distinct ones -- about 0.7 per node
+// in the wide levels, where neighbouring nodes share blocks -- are numbered by two ballots, their numbers listed in LDS, and
+// fetched by groups of four lanes, one 16-byte quarter each: a block is ONE 64-byte request of one load instruction instead of
+// four quarter requests in four instructions, repeated by every lane that shares it.  (The kernel is bound by the requests its
+// waves issue, not by bytes.)  Word w of the staging area = quarter w & 3 of distinct block w >> 2; lanes then read the blocks
+// they need -- for the four-base ranks and again for the left-extension ranks -- from there.
+constexpr u32 STAGE_BLOCKS = 128;                        // distinct blocks of a tile: at most two per lane
+constexpr u32 WAVE_LDS_WORDS = STAGE_BLOCKS * 4 + 32;    // uint4 per wave: the staged blocks, then the list of their numbers (8.5 KB)
+__device__ __forceinline__ void staged_blk(const uint4* wl, u32 idx, Blk16& r) {
+    const uint4 h = wl[idx * 4 + 0], a = wl[idx * 4 + 1], c = wl[idx * 4 + 2], d = wl[idx * 4 + 3];
+    r.cnt[0] = h.x; r.cnt[1] = h.y; r.cnt[2] = h.z; r.cnt[3] = h.w;
+    r.p0a = ((u64)a.y << 32) | a.x; r.p0b = ((u64)a.w << 32) | a.z;
+    r.p1a = ((u64)c.y << 32) | c.x; r.p1b = ((u64)c.w << 32) | c.z;
+    r.p2a = ((u64)d.y << 32) | d.x; r.p2b = ((u64)d.w << 32) | d.z;
 }
 template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_parked(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 which, int lane, u64 x, u32 c) {
-    const uint4 q1 = wl[(which * 4 + 1) * 64 + lane], q2 = wl[(which * 4 + 2) * 64 + lane], q3 = wl[(which * 4 + 3) * 64 + lane];
-    const u32 cntc = reinterpret_cast<const u32*>(wl + (which * 4 + 0) * 64 + lane)[c];
+__device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 idx, u64 x, u32 c) {
+    const uint4 q1 = wl[idx * 4 + 1], q2 = wl[idx * 4 + 2], q3 = wl[idx * 4 + 3];
+    const u32 cntc = reinterpret_cast<const u32*>(wl + idx * 4)[c];
     return rank_one<P, ONESB>(sa, sbl, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z, ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z,
                               ((u64)q3.y << 32) | q3.x, ((u64)q3.w << 32) | q3.z, cntc, x, c);
 }
@@ -329,15 +334,47 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const P sp = nd.sp, ep = nd.ep;
     const u32 emask = nd.emask;
     const u32 ne = __popc(emask);
-    // both ends of the interval are requested before anything waits (absent nodes: sp = 1, ep = 0 -> block 0, twice)
-    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;
+    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;  // blocks of the two interval ends
     u32 n_lf = 0, n_rank = 0, lines = 0;
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
+    u32 idx0, idx1;   // numbers of this lane's two blocks among the tile's distinct blocks
     {
-        Blk16 r0, r1;      // blocks of sp and of ep + 1
-        load_blk(ix.blk, b0, r0);
-        load_blk(ix.blk, b1, r1);
+        // ---- the distinct blocks of the tile (see the staging note above) ----
+        u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
+        u32 pm = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane; running maximum over the lanes below = the last block listed
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
+        u32 prev = __shfl_up(pm, 1, 64);
+        if (lane == 0) prev = 0;
+        const bool f0 = live && (u32)b0 + 1u > prev, f1 = live && b1 != b0;
+        const u64 m0 = __ballot(f0), m1 = __ballot(f1);
+        const u32 D = (u32)__popcll(m0) + (u32)__popcll(m1);
+        const u32 before = bits_below_lane(m0) + bits_below_lane(m1);
+        idx0 = f0 ? before : (before ? before - 1u : 0u);
+        idx1 = f1 ? idx0 + 1u : idx0;
+        if (!live) { idx0 = 0; idx1 = 0; }
+        lines = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+        if (f0) list[idx0] = (u32)b0;
+        if (f1) list[idx1] = (u32)b1;
+        if (D == 0 && lane == 0) list[0] = 0;
+        const u32 Dm1 = D ? D - 1u : 0u;
+        const u32 g = (u32)lane >> 2, qq = (u32)lane & 3u;
+        // four lanes per block, sixteen blocks per instruction; lanes beyond the last block repeat it
+        uint4 v0, v1, v2, v3;
+        {
+            const u32 d0 = g < Dm1 ? g : Dm1, d1 = g + 16 < Dm1 ? g + 16 : Dm1, d2 = g + 32 < Dm1 ? g + 32 : Dm1, d3 = g + 48 < Dm1 ? g + 48 : Dm1;
+            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
+            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
+            v0 = base[(size_t)bb0 * 4 + qq]; v1 = base[(size_t)bb1 * 4 + qq]; v2 = base[(size_t)bb2 * 4 + qq]; v3 = base[(size_t)bb3 * 4 + qq];
+        }
+        if (D > 64) {  // (wave-uniform) the rarer second half
+            const u32 d0 = g + 64 < Dm1 ? g + 64 : Dm1, d1 = g + 80 < Dm1 ? g + 80 : Dm1, d2 = g + 96 < Dm1 ? g + 96 : Dm1, d3 = g + 112 < Dm1 ? g + 112 : Dm1;
+            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
+            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
+            const uint4 w0 = base[(size_t)bb0 * 4 + qq], w1 = base[(size_t)bb1 * 4 + qq], w2 = base[(size_t)bb2 * 4 + qq], w3 = base[(size_t)bb3 * 4 + qq];
+            wl[256 + lane] = w0; wl[320 + lane] = w1; wl[384 + lane] = w2; wl[448 + lane] = w3;
+        }
         // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
         // the blocks leaves them in flight) ----
         load_head<P>(rec, cap, rn, hn);
@@ -348,13 +385,15 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             const u32 v = rp[in2 ? i2 : 0u];
             rn = in2 ? v : DEAD;
         }
-        // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty,
-        // and straight-line code keeps the compiler from sinking the block loads behind the prefetches.
+        wl[lane] = v0; wl[64 + lane] = v1; wl[128 + lane] = v2; wl[192 + lane] = v3;
+        asm volatile("" ::: "memory");  // the blocks are read back from LDS (other lanes' words among them)
+        // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty.
+        Blk16 r0;
+        staged_blk(wl, idx0, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)sp, Rsp);  // LF(c, sp-1)
         const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-        rank4_blk<P, ONESB>(a.sb, sbl, r1, (u64)ep + 1, Rep);  // LF(c, ep)
-        park_blk(wl, 0, lane, r0);
-        park_blk(wl, 1, lane, r1);
+        staged_blk(wl, idx1, r0);
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         if (single && a.allowed) n_rank += (a.access_pack >> (4 * lcode)) & 15u;
 #pragma unroll
@@ -373,17 +412,6 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             }
         }
         if (!live) { n_lf = 0; n_rank = 0; present = 0; }
-    }
-    asm volatile("" ::: "memory");  // what follows reads the blocks from LDS, not from registers kept alive across the rounds
-    {   // index lines this wave asks for at the interval ends: intervals are disjoint and increasing along the lanes, so a
-        // block is new to the wave iff it lies beyond every block of the lower lanes (lanes that share a block share the line)
-        const u32 bend = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane
-        u32 pm = bend;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
-        u32 prev = __shfl_up(pm, 1, 64);
-        if (lane == 0) prev = 0;
-        if (live) lines += ((u32)b0 + 1u > prev ? 1u : 0u) + ((b1 != b0 && (u32)b1 + 1u > prev) ? 1u : 0u);
     }
     // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
     const u32 k = __popc(present);
@@ -451,14 +479,14 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             if (__any(needl)) {
                 if (needl) {
                     const u64 bl = xl >> BLK_SHIFT;
-                    if (bl == b0 || bl == b1) l = rank_parked<P, ONESB>(a.sb, sbl, wl, bl != b0 ? 1u : 0u, lane, xl, c);
+                    if (bl == b0 || bl == b1) l = rank_staged<P, ONESB>(a.sb, sbl, wl, bl != b0 ? idx1 : idx0, xl, c);
                     else { l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c); ++lines; }
                 }
             }
             if (__any(needh)) {
                 if (needh) {
                     const u64 bh = xh >> BLK_SHIFT;
-                    if (bh == b0 || bh == b1) h = rank_parked<P, ONESB>(a.sb, sbl, wl, bh != b0 ? 1u : 0u, lane, xh, c);
+                    if (bh == b0 || bh == b1) h = rank_staged<P, ONESB>(a.sb, sbl, wl, bh != b0 ? idx1 : idx0, xh, c);
                     else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
                 }
             }
@@ -2041,6 +2069,7 @@ class Engine {
         // The expand launch of a level is queued as early as possible: for level L+1 right after the synchronisation of
         // level L, ahead of that level's remaining small launches (order, candidate store), so the GPU does not wait for
         // the host to get through them.
+        const bool trace_levels = getenv("DSM_TRACE_LEVELS") != nullptr;  // debugging aid: widths of the levels on stderr
         bool fmt_in = false;  // format of the records of the level about to be expanded (the root's record is wide)
         auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16) -> int {
             // ---- expand ---------------------------------------------------------------------------
@@ -2275,6 +2304,7 @@ class Engine {
                 else if (erc) return erc;
             }
             DSM_HIP(hipGetLastError());
+            if (trace_levels) fprintf(stderr, "dsm level prefix=%s depth=%u F=%u\n", prefix.c_str(), depth, F);
             stats.union_nodes += depth >= 1 ? F : 0;
             if (F > stats.max_frontier) stats.max_frontier = F;
             ++stats.levels;
