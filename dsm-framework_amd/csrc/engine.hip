@@ -456,6 +456,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         }
         u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
         P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
+        P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
 #pragma nounroll
         for (u32 p = 0; __any(p < npair); ++p) {
             const bool act = p < npair;
@@ -475,7 +476,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             }
             const u64 xl = hasext ? (u64)xmin : (u64)sp, xh = hasext ? (u64)xmax + 1 : (u64)ep + 1;
             P l = nsp, h = nep1;
-            const bool needl = xl != (u64)sp, needh = xh != (u64)ep + 1;
+            bool needl = xl != (u64)sp;
+            const bool needh = xh != (u64)ep + 1;
+            if (e > 0 && xl == prevx) { l = prevh; needl = false; }  // adjacent intervals share an end: the rank is the previous pair's
             if (__any(needl)) {
                 if (needl) {
                     const u64 bl = xl >> BLK_SHIFT;
@@ -490,6 +493,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                     else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
                 }
             }
+            prevx = (P)xh; prevh = h;
             if (hasext && l <= h - 1) {
                 if (cn == 0) { kl0 = l; kh0 = h - 1; }
                 else if (cn == 1) { kl1 = l; kh1 = h - 1; }
@@ -676,31 +680,33 @@ struct AdvanceOut {
     u32* h_totals;       // single-tile levels: [0] = nodes of the new level (larger levels: the grand total of the scan)
 };
 
-// The few words the host reads after a level go to pinned host memory in one tiny launch.  A large kernel that wrote them
-// itself would end with a system-scope release of everything it left dirty in L2.
+// The few words the host reads after a level travel as ONE 16-byte store to pinned host memory: {sequence number, width of
+// the new level | wide-frequency flag << 31, candidates, pairs}.  A naturally aligned 16-byte store is one write on the bus, so
+// the host that sees the sequence number sees the rest -- no system-scope fence whose completion the kernel would wait for.
+// (A large kernel that wrote to host memory itself would end with a system-scope release of everything it left dirty in L2.)
 struct PublishArgs {
-    const u32* src[4];
-    u32* dst[4];
-    u32 words[4];
+    const u32* total;     // width of the new level
+    const u64* cand;      // candidates | pairs << 32 of the level just filtered (null: not filtered)
     const u8* cmax_base;  // exchange buffer of the level: rank r's message starts with the largest child frequency it saw
     u64 cmax_bpr;
-    u64* cmax_dst;        // pinned, one per rank
     u32 cmax_world;
-    u32* clear;   // header of the message the next level's expand kernels will fill (4 words), may be null
-    u32* flag;    // pinned: receives `seq` after everything above is visible to the host (the host spins on it)
+    u32* clear;           // header of the message the next level's expand kernels will fill (4 words), may be null
+    uint4* packet;        // pinned, 16-byte aligned
     u32 seq;
 };
 __global__ void publish_kernel(PublishArgs a) {
-    for (u32 r = threadIdx.x; r < a.cmax_world; r += blockDim.x)
-        a.cmax_dst[r] = *reinterpret_cast<const u64*>(a.cmax_base + (u64)r * a.cmax_bpr);
-    __syncthreads();  // (the header that is cleared next may be the one just read: single process, alternating buffers do not alias, but keep the order)
-    if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        for (u32 q = threadIdx.x; q < a.words[k]; q += blockDim.x) a.dst[k][q] = a.src[k][q];
-    __threadfence_system();
+    __shared__ u32 wide;
+    if (threadIdx.x == 0) wide = 0;
     __syncthreads();
-    if (threadIdx.x == 0 && a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (u32 r = threadIdx.x; r < a.cmax_world; r += blockDim.x)
+        if (*reinterpret_cast<const u64*>(a.cmax_base + (u64)r * a.cmax_bpr) >= 65535) wide = 1;
+    const u32 tot = threadIdx.x == 0 ? *a.total : 0u;
+    const u64 cand = threadIdx.x == 0 && a.cand ? *a.cand : 0ull;
+    __syncthreads();
+    if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        *a.packet = make_uint4(a.seq, tot | (wide << 31), (u32)cand, (u32)(cand >> 32));  // one global_store_dwordx4
+    }
 }
 
 // Down-sweep, one thread per parent, one tile of 256 parents per block (the tiles of the expand kernel).  A child's index in
@@ -2221,21 +2227,20 @@ class Engine {
             {
                 PublishArgs pa;
                 memset(&pa, 0, sizeof pa);
-                pa.src[0] = nbp == 1 ? d_pub_tot : d_totals; pa.dst[0] = h_totals; pa.words[0] = 1;  // new level's width: from the single tile, or the scan's total
-                pa.cmax_base = x.base; pa.cmax_bpr = x.bpr; pa.cmax_dst = h_childmax; pa.cmax_world = (u32)world;
-                if (filtered) {
-                    pa.src[3] = reinterpret_cast<const u32*>(d_totals64); pa.dst[3] = h_totals + 300; pa.words[3] = 2u;
-                }
+                pa.total = nbp == 1 ? d_pub_tot : d_totals;  // new level's width: from the single tile, or the scan's total
+                pa.cmax_base = x.base; pa.cmax_bpr = x.bpr; pa.cmax_world = (u32)world;
+                if (filtered) pa.cand = d_totals64;
                 pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
-                pa.flag = h_totals + 310; pa.seq = ++pub_seq;
-                hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, st, pa);
+                pa.packet = reinterpret_cast<uint4*>(h_totals + 304); pa.seq = ++pub_seq;
+                hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, pa);
             }
-            {   // the publish kernel is the last work queued: its flag in pinned memory is this level's completion.  Spinning on
+            u32 pk[4];
+            {   // the publish kernel is the last work queued: its packet in pinned memory is this level's completion.  Spinning on
                 // it returns a few microseconds after the store; a stream synchronisation wakes the thread later.
-                volatile u32* fl = h_totals + 310;
+                volatile u32* fl = h_totals + 304;
                 u32 spins = 0;
                 while (*fl != pub_seq) {
-                    if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the flag?
+                    if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the packet?
                         DSM_HIP(hipStreamSynchronize(st));
                         if (*fl != pub_seq) return fail(DSM_E_HIP, "publish kernel did not report");
                         break;
@@ -2243,13 +2248,11 @@ class Engine {
                     __builtin_ia32_pause();
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
+                for (int q = 0; q < 4; ++q) pk[q] = fl[q];
             }
-            const u32 Fn = h_totals[0];
-            {
-                u64 mx = 0;
-                for (int r = 0; r < world; ++r) mx = h_childmax[r] > mx ? h_childmax[r] : mx;
-                w16 = mx < 65535 && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
-            }
+            const u32 Fn = pk[1] & 0x7FFFFFFFu;
+            w16 = !(pk[1] >> 31) && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
+            h_totals[300] = pk[2]; h_totals[301] = pk[3];  // candidate totals of this level (read by emit_store)
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             // commit the provisional window at its real size
             arena.off = mark2;
