@@ -200,7 +200,7 @@ def main():
             ln["ex"].gate = gate
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
-           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "ext_read": 0, "slots": 0, "colbytes": 0}
+           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0}
     import threading
     tot_lock = threading.Lock()
 
@@ -232,7 +232,7 @@ def main():
                     tot["cand"] += st.candidates
                     tot["index_lines"] += st.index_lines
                     tot["records_read"] += st.records_read
-                    tot["ext_read"] += st.ext_read
+                    tot["record_bytes"] += st.record_bytes
                     tot["slots"] += st.expand_slots
                     tot["colbytes"] += st.expand_column_bytes
         except Exception as e:  # noqa: BLE001
@@ -302,12 +302,10 @@ def main():
         ln["miner"].close()
 
     if rank == 0:
-        # Bytes the LF-step kernel moves, from its own exact counters: 64 B per index block a wave asks
-        # for, per thread a 4-byte record handle, its column entry and 0.5 B of child planes, per record read or written
-        # sp, ep and the mask byte, per left-extension interval read or written its two ends.
-        pbytes = 8 if (args.wide or ix.n >= 0xFFFFFFF0) else 4
-        kernel_bytes = (64 * tot["index_lines"] + 4 * tot["slots"] + tot["slots"] // 2 + tot["colbytes"]
-                        + (tot["records_read"] + tot["reported"]) * (2 * pbytes + 1) + 2 * tot["ext_read"] * 2 * pbytes)
+        # Bytes the LF-step kernel moves, from its own exact counters: 64 B per distinct index block of a
+        # tile, per thread a 4-byte record handle, its column entry and 0.5 B of child planes, and the records it read and wrote
+        # (16-byte compact words in all but the top levels of a prefix).
+        kernel_bytes = 64 * tot["index_lines"] + 4 * tot["slots"] + tot["slots"] // 2 + tot["colbytes"] + tot["record_bytes"]
         esec = tot["expand_ms"] * 1e-3
         ach = kernel_bytes / esec / 1e9 if esec > 0 else 0.0
         ref_equiv = tot["rank_ops"] * ALG_BYTES_PER_RANK / esec / 1e9 if esec > 0 else 0.0

@@ -152,7 +152,7 @@ constexpr int REC_FIELDS = 10;
 template <typename P>
 __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
-constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=ext intervals read [5]=records read
+constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=record bytes read + written [5]=records read
 constexpr u32 DEAD = 0xFFFFFFFFu;
 constexpr u32 TILE = 256;             // parents per block of the expand / advance kernels
 
@@ -312,8 +312,9 @@ __device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32
 }
 
 struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
-    // (k <= 4, ne <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
+    // (k <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
     u32 kne = 0, ll = 0, lf = 0, rank = 0;
+    u32 rbytes = 0;     // bytes of records read and written
     bool wide = false;  // some surviving child has a frequency of 65535 or more (decides the next level's column width)
 };
 
@@ -339,6 +340,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
     u32 idx0, idx1;   // numbers of this lane's two blocks among the tile's distinct blocks
+    u32 rb_out = 0;   // bytes of child records this lane writes
     {
         // ---- the distinct blocks of the tile (see the staging note above) ----
         u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
@@ -457,6 +459,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
         P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
         P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
+        rb_out = 0;
 #pragma nounroll
         for (u32 p = 0; __any(p < npair); ++p) {
             const bool act = p < npair;
@@ -501,7 +504,11 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                 ++cn;
                 cm |= 1u << kk;
             }
-            if (act && e == ne1 - 1) store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
+            if (act && e == ne1 - 1) {
+                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
+                rb_out += (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1) + (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P)) +
+                          (cn > 2 ? (cn - 2) * 2u * (u32)sizeof(P) : 0u);
+            }
         }
     }
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
@@ -511,7 +518,10 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
         pl[i] = (u8)(present | (mycode << 4));
     }
-    acc.kne += k | (ne << 16); acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
+    acc.kne += k; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
+    // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
+    // when in use) and its children's (compact word each, or their fields; rb_out collected by the rounds)
+    acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
 }
 
 template <typename P, bool ONESB, bool INC, bool OUTC>
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __r
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
     if (__any(acc.wide) && lane == 0) atomicMax(childmax, 65535ull);  // only "65535 or more" matters (and it is rare)
     {
-        u64 v[NCOUNTERS] = {acc.kne & 0xFFFFu, acc.lf, acc.rank, acc.ll >> 16, acc.kne >> 16, acc.ll & 0xFFFFu};
+        u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
 #pragma unroll
         for (int q = 0; q < NCOUNTERS; ++q) v[q] = wave_sum_u64(v[q]);
         if (lane < NCOUNTERS) {
@@ -2219,7 +2229,7 @@ class Engine {
                 if (!merged) ao.cnt_clear = cntraw;
             }
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
-            else hipLaunchKernelGGL((advance_wave_kernel<P>), grid_npt(F), dim3(256), 0, st, x, ao);
+            else hipLaunchKernelGGL((advance_wave_kernel<P>), grid_for(F), dim3(256), 0, st, x, ao);
             // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
@@ -2361,7 +2371,7 @@ class Engine {
         stats.lf_steps += hc[1];
         stats.rank_ops += hc[2];
         stats.index_lines += hc[3];
-        stats.ext_read += hc[4];
+        stats.record_bytes += hc[4];
         stats.records_read += hc[5];
         return 0;
     }

@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("tuples", C.c_uint64), ("pairs", C.c_uint64), ("candidates", C.c_uint64), ("levels", C.c_uint64),
                 ("max_frontier", C.c_uint64), ("expand_launches", C.c_uint64), ("expand_ms", C.c_double),
                 ("device_ms", C.c_double), ("host_ms", C.c_double), ("pair_order_exact", C.c_uint64), ("splits", C.c_uint64),
-                ("index_lines", C.c_uint64), ("records_read", C.c_uint64), ("ext_read", C.c_uint64), ("expand_slots", C.c_uint64),
+                ("index_lines", C.c_uint64), ("records_read", C.c_uint64), ("record_bytes", C.c_uint64), ("expand_slots", C.c_uint64),
                 ("expand_column_bytes", C.c_uint64)]
 
     def as_dict(self):

@@ -115,7 +115,7 @@ typedef struct dsm_stats {
     /* exact memory work of the LF-step (expand) kernel, counted by the kernel itself (ABI version 2) */
     uint64_t index_lines;    /* 64-byte index blocks it fetched */
     uint64_t records_read;   /* frontier records it read (nodes present in the sample) */
-    uint64_t ext_read;       /* left-extension intervals it read = intervals the previous level wrote */
+    uint64_t record_bytes;   /* bytes of frontier records it read and wrote (compact 16-byte words, or the wide fields) */
     uint64_t expand_slots;   /* threads it ran = frontier nodes x local samples (absent nodes only cost their handle and column entry) */
     uint64_t expand_column_bytes; /* bytes of exchange column it wrote */
 } dsm_stats;
