@@ -1,20 +1,36 @@
-// dsm_node -- fused single-process driver: all samples of one node, enumeration + merge + entropy filter on the
-// GPU(s) of this process, reference-format tuples out (what N metaenumerate clients + one metaserver per prefix
-// produce, metaserver.cpp:467-485).  Sample ids follow the order of the index files (the server's names order).
-//   dsm_node -E emax [-e emin] [-P pmin] [--pmax N] [-m mindepth] [-f fmin] [-M maxdepth] [--device D]
-//            [--out-prefix path.] -p PREFIX[,PREFIX...] a.fmi b.fmi ...
+// dsm_node -- fused driver for one node: all samples, enumeration + merge + entropy filter on the GPUs, reference-format
+// tuples out (what N metaenumerate clients + one metaserver per prefix produce, metaserver.cpp:467-485).
+// Sample ids follow the order of the index files (the server's names order).
+//   dsm_node -E emax [-e emin] [-P pmin] [--pmax N] [-m mindepth] [-f fmin] [-M maxdepth]
+//            [--device D | --devices D0,D1,...] [--out-prefix path.] -p PREFIX[,PREFIX...] a.fmi b.fmi ...
+// One device: one miner holds every index.  Several devices (--devices): the reference's fan-out -- one metaenumerate per
+// sample (wrapper-SLURM/example-client.sh:27-30), one socket and one server per prefix (metaenumerate.cpp:268-309) -- becomes
+// one thread + HIP stream per GPU inside this process, the samples dealt out in blocks (sample k lives on device k / (d / G)),
+// and ONE ncclAllGather (RCCL over xGMI) per frontier level, issued on the engine's stream from the library's exchange
+// callback.  Prefix k is filtered, ordered and emitted by device k mod G only; the outputs are written in prefix order.
 // With --out-prefix every prefix goes to <out-prefix><PREFIX>.txt (server-wrapper.sh:35 naming), else to stdout.
 #include <getopt.h>
+#include <unistd.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsmhip.h"
+
+// stdout carries the tuples.  Libraries underneath (the collective library prints a version banner) must not write into them:
+// the tuples go to a private copy of the descriptor, and descriptor 1 is pointed at stderr.
+static FILE* g_out = nullptr;
+
+static const char* USAGE = "usage: dsm_node -E emax [options] [--devices D0,D1,..] -p PREFIX[,PREFIX..] a.fmi b.fmi ...";
 
 static int to_file(void* ctx, const dsm_tuple_batch* b) {
     char* text = nullptr;
@@ -25,17 +41,131 @@ static int to_file(void* ctx, const dsm_tuple_batch* b) {
     return w != len;
 }
 
+// ---- several devices ---------------------------------------------------------------------------------------------------
+struct Rank {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<std::string> files;          // this rank's samples, in id order
+    const std::vector<std::string>* prefixes = nullptr;
+    std::vector<std::string>* out = nullptr; // one text per prefix, filled by the prefix's owner
+    dsm_params p;
+    std::string err;
+    dsm_stats st;
+};
+
+// dsm_allgather_fn: every rank contributes `bytes` bytes, receives world * bytes, rank-major; ordered on the engine's stream
+static int rccl_allgather(void* ctx, const void* send, void* recv, size_t bytes, void* stream) {
+    Rank* r = (Rank*)ctx;
+    return ncclAllGather(send, recv, bytes, ncclUint8, r->comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+// The tuples of a prefix start with the prefix: a batch goes to the output of the (longest) prefix its first path starts with.
+static int to_prefix_text(void* ctx, const dsm_tuple_batch* b) {
+    Rank* r = (Rank*)ctx;
+    if (!b->ntuples) return 0;
+    const char* path = b->path_bytes + b->path_off[0];
+    const size_t plen = b->path_off[1] - b->path_off[0];
+    int best = -1;
+    for (size_t k = 0; k < r->prefixes->size(); ++k) {
+        const std::string& pre = (*r->prefixes)[k];
+        if ((int)(k % r->world) != r->rank) continue;  // only prefixes this rank owns arrive here
+        if (pre.size() <= plen && memcmp(pre.data(), path, pre.size()) == 0 && (best < 0 || pre.size() > (*r->prefixes)[best].size())) best = (int)k;
+    }
+    if (best < 0) return 1;
+    char* text = nullptr;
+    size_t len = 0;
+    if (dsm_format_batch(b, &text, &len)) return 1;
+    (*r->out)[best].append(text, len);
+    dsm_free(text);
+    return 0;
+}
+
+static void run_rank(Rank* r) {
+    auto fail = [&](const std::string& m) { r->err = m; };
+    if (hipSetDevice(r->device) != hipSuccess) return fail("hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    std::vector<dsm_index*> idx;
+    for (const std::string& f : r->files) {
+        dsm_index* ix = nullptr;
+        if (dsm_index_open(f.c_str(), r->device, &ix)) { fail(f + ": " + dsm_last_error()); break; }
+        idx.push_back(ix);
+    }
+    // Every rank must reach the collectives of miner creation, or the others hang: a rank that failed above still cannot take
+    // part without its indexes, so the whole job is aborted by the caller when any rank reports an error before this point.
+    dsm_miner* m = nullptr;
+    if (r->err.empty()) {
+        dsm_params p = r->p;
+        p.world_size = (uint32_t)r->world;
+        p.rank = (uint32_t)r->rank;
+        p.allgather = rccl_allgather;
+        p.allgather_ctx = r;
+        p.emit_owner_only = 1;
+        p.stream = r->stream;
+        if (dsm_miner_create(idx.data(), (int)idx.size(), &p, 0, &m)) fail(std::string("miner: ") + dsm_last_error());
+    }
+    if (m) {
+        std::vector<const char*> pre;
+        for (const std::string& s : *r->prefixes) pre.push_back(s.c_str());
+        if (dsm_miner_mine_many(m, pre.data(), (int)pre.size(), to_prefix_text, r, &r->st)) fail(std::string("mine: ") + dsm_last_error());
+        dsm_miner_destroy(m);
+    }
+    for (auto* ix : idx) dsm_index_close(ix);
+    (void)hipStreamDestroy(r->stream);
+}
+
+static int run_devices(const std::vector<int>& devs, const dsm_params& p, const std::vector<std::string>& prefixes,
+                       const std::vector<std::string>& files, const std::string& outprefix) {
+    const int G = (int)devs.size();
+    if (files.size() % G) { std::cerr << "dsm_node: the number of samples must be a multiple of the number of devices" << std::endl; return 1; }
+    const size_t nlocal = files.size() / G;
+    std::vector<ncclComm_t> comms(G);
+    if (ncclCommInitAll(comms.data(), G, devs.data()) != ncclSuccess) { std::cerr << "dsm_node: ncclCommInitAll failed" << std::endl; return 1; }
+    std::vector<std::string> out(prefixes.size());
+    std::vector<Rank> ranks(G);
+    for (int r = 0; r < G; ++r) {
+        ranks[r].rank = r; ranks[r].world = G; ranks[r].device = devs[r]; ranks[r].comm = comms[r];
+        ranks[r].files.assign(files.begin() + r * nlocal, files.begin() + (r + 1) * nlocal);
+        ranks[r].prefixes = &prefixes; ranks[r].out = &out; ranks[r].p = p;
+    }
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; ++r) th.emplace_back(run_rank, &ranks[r]);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < G; ++r) (void)ncclCommDestroy(comms[r]);
+    int rc = 0;
+    for (int r = 0; r < G; ++r)
+        if (!ranks[r].err.empty()) { std::cerr << "dsm_node: device " << devs[r] << ": " << ranks[r].err << std::endl; rc = 1; }
+    if (rc) return rc;
+    for (size_t k = 0; k < prefixes.size(); ++k) {
+        FILE* f = g_out;
+        if (!outprefix.empty()) {
+            f = fopen((outprefix + prefixes[k] + ".txt").c_str(), "w");
+            if (!f) { std::cerr << "cannot open output for prefix " << prefixes[k] << std::endl; return 1; }
+        }
+        fwrite(out[k].data(), 1, out[k].size(), f);
+        if (f != g_out) fclose(f);
+    }
+    uint64_t nodes = 0, tuples = 0;
+    for (int r = 0; r < G; ++r) { nodes += ranks[r].st.reported; tuples += ranks[r].st.tuples; }
+    fflush(g_out);
+    std::cerr << G << " device(s): " << nodes << " nodes, " << ranks[0].st.union_nodes << " paths, " << tuples << " reported" << std::endl;
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    fflush(stdout);
+    g_out = fdopen(dup(1), "w");
+    if (!g_out || dup2(2, 1) < 0) { std::cerr << "dsm_node: cannot set up the output" << std::endl; return 1; }
     dsm_params p;
     dsm_params_default(&p);
-    std::string prefixes = "", outprefix = "";
+    std::string prefixes = "", outprefix = "", devlist = "";
     int device = 0;
     static option long_options[] = {{"pmin", required_argument, 0, 'P'},     {"pmax", required_argument, 0, 258},
                                     {"mindepth", required_argument, 0, 'm'}, {"emin", required_argument, 0, 'e'},
                                     {"emax", required_argument, 0, 'E'},     {"fmin", required_argument, 0, 'f'},
                                     {"maxdepth", required_argument, 0, 'M'}, {"prefix", required_argument, 0, 'p'},
                                     {"device", required_argument, 0, 257},   {"out-prefix", required_argument, 0, 259},
-                                    {0, 0, 0, 0}};
+                                    {"devices", required_argument, 0, 260},  {0, 0, 0, 0}};
     int c, oi = 0;
     while ((c = getopt_long(argc, argv, "P:m:e:E:f:M:p:", long_options, &oi)) != -1) {
         switch (c) {
@@ -49,12 +179,28 @@ int main(int argc, char** argv) {
             case 'p': prefixes = optarg; break;
             case 257: device = atoi(optarg); break;
             case 259: outprefix = optarg; break;
-            default: std::cerr << "usage: dsm_node -E emax [options] -p PREFIX[,PREFIX..] a.fmi b.fmi ..." << std::endl; return 1;
+            case 260: devlist = optarg; break;
+            default: std::cerr << USAGE << std::endl; return 1;
         }
     }
     if (p.emax < 0) { std::cerr << argv[0] << ": error: expecting parameter --emax" << std::endl; return 1; }  // metaserver.cpp:582-586
     if (p.emin > p.emax) { std::cerr << argv[0] << ": error: -e <double> must be smaller than or equal to -E <double>" << std::endl; return 1; }
-    if (prefixes.empty() || optind >= argc) { std::cerr << "usage: dsm_node -E emax [options] -p PREFIX[,PREFIX..] a.fmi b.fmi ..." << std::endl; return 1; }
+    if (prefixes.empty() || optind >= argc) { std::cerr << USAGE << std::endl; return 1; }
+    std::vector<std::string> pre;
+    {
+        std::stringstream ss(prefixes);
+        std::string one;
+        while (std::getline(ss, one, ',')) pre.push_back(one);
+    }
+    if (!devlist.empty()) {
+        std::vector<int> devs;
+        std::stringstream ss(devlist);
+        std::string one;
+        while (std::getline(ss, one, ',')) devs.push_back(atoi(one.c_str()));
+        std::vector<std::string> files(argv + optind, argv + argc);
+        if (devs.empty()) { std::cerr << USAGE << std::endl; return 1; }
+        return run_devices(devs, p, pre, files, outprefix);
+    }
     std::vector<dsm_index*> idx;
     for (int k = optind; k < argc; ++k) {
         dsm_index* ix = nullptr;
@@ -63,19 +209,18 @@ int main(int argc, char** argv) {
     }
     dsm_miner* m = nullptr;
     if (dsm_miner_create(idx.data(), (int)idx.size(), &p, 0, &m)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
-    std::stringstream ss(prefixes);
-    std::string pre;
-    while (std::getline(ss, pre, ',')) {
-        FILE* out = stdout;
+    for (const std::string& one : pre) {
+        FILE* out = g_out;
         if (!outprefix.empty()) {
-            out = fopen((outprefix + pre + ".txt").c_str(), "w");
-            if (!out) { std::cerr << "cannot open output for prefix " << pre << std::endl; return 1; }
+            out = fopen((outprefix + one + ".txt").c_str(), "w");
+            if (!out) { std::cerr << "cannot open output for prefix " << one << std::endl; return 1; }
         }
         dsm_stats st;
-        if (dsm_miner_mine(m, pre.c_str(), to_file, out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
-        if (out != stdout) fclose(out);
-        std::cerr << "prefix " << pre << ": " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported" << std::endl;
+        if (dsm_miner_mine(m, one.c_str(), to_file, out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+        if (out != g_out) fclose(out);
+        std::cerr << "prefix " << one << ": " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported" << std::endl;
     }
+    fflush(g_out);
     dsm_miner_destroy(m);
     for (auto* ix : idx) dsm_index_close(ix);
     return 0;

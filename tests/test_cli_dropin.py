@@ -34,6 +34,29 @@ def test_dsm_node_prints_reference_tuples(golden):
     assert r.returncode == 1 and b"expecting parameter --emax" in r.stderr
 
 
+def test_dsm_node_device_list_runs_the_exchange_on_rccl(golden, tmp_path):
+    """--devices: one thread + stream per GPU, ncclAllGather from the library's exchange callback (no Python on the path).  One
+    card is all a test box has, so the world is one rank -- DSM_FORCE_EXCHANGE sends every level through the collective anyway
+    (send buffer, RCCL all-gather, status words, owner-only emission)."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    fmis = [golden.fmi("toy3", n) for n in names]
+    ps = ["A", "C", "GT", "TTG"]
+    want = b"".join(golden.server_out("toy3", "default", p) for p in ps)
+    for env in (dict(os.environ, DSM_FORCE_EXCHANGE="1"), dict(os.environ)):
+        r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0", "-E", "2.0", "-f", "2", "-p", ",".join(ps)] + fmis,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want
+    r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0", "-E", "2.0", "-f", "2", "--out-prefix", str(tmp_path / "o."), "-p", "A,GT"] + fmis,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for p in ("A", "GT"):
+        assert open(tmp_path / ("o." + p + ".txt"), "rb").read() == golden.server_out("toy3", "default", p)
+    # samples must divide evenly among the devices
+    r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0,0", "-E", "2.0", "-p", "A"] + fmis, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"multiple of the number of devices" in r.stderr
+
+
 def test_check_mode(golden):
     r = subprocess.run([os.path.join(HOST, "metaenumerate_hip"), "--check", golden.fmi("toy3", "toy-1")], input=b"localhost 5000 A\n",
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
