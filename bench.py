@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal at N=1: drive the whole multi-rank exchange path (send buffer, "
                     "one RCCL all-gather per level through torch.distributed, lanes, status words) with a world of one")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra records of the default N=1 run (64-bit positions; eight samples on one GPU)")
     ap.add_argument("--pmin", type=int, default=-1, help="metaserver -P; default 1 for a single sample, else 2")
     ap.add_argument("--pmax", type=int, default=0, help="metaserver --pmax (BASELINE configs[3]: 8, configs[4]: 1)")
     ap.add_argument("--wide", action="store_true", help="force 64-bit positions (the code path of n > 2^32, BASELINE configs[3])")
@@ -87,7 +88,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(path, args, pmin):
+def cpu_baseline(path, args, pmin, seconds=None):
     """The oracle (our restatement of the reference client+server, same 3-array layout, one OpenMP thread per
     prefix like metaenumerate.cpp:268, one in-process server per prefix) timed on a bounded sample of the same
     workload: 6-mer prefixes of the same index, in random order, until the time budget is used."""
@@ -98,7 +99,8 @@ def cpu_baseline(path, args, pmin):
     allp = ["".join(p) for p in itertools.product("ACGT", repeat=6)]
     random.Random(1).shuffle(allp)
     done, nodes, t0 = 0, 0, time.time()
-    while done < len(allp) and time.time() - t0 < args.cpu_seconds:
+    budget = args.cpu_seconds if seconds is None else seconds
+    while done < len(allp) and time.time() - t0 < budget:
         batch = allp[done:done + threads]
         _, st = orc.mine([ix], ["sample-0"], batch, fmin=args.fmin, pmin=pmin, emax=args.emax, threads=threads, discard=True)
         nodes += st[0]
@@ -108,6 +110,116 @@ def cpu_baseline(path, args, pmin):
     return {"value": nodes / dt, "unit": "substrings/s", "cores": threads, "kind": "port",
             "sample": "%d random 6-mer prefixes of 4096 of the same index (client enumeration + in-process merge/filter, "
                       "one OpenMP thread per prefix), %d nodes in %.1f s" % (done, nodes, dt)}
+
+
+def cpu_baseline_reference(path, args, ix, pydsm):
+    """The UNMODIFIED reference client (oracle/_ref/metaenumerate, built from /root/reference by oracle/Makefile.ref; it travels to
+    the GPU box as a binary) on a bounded sample of the same workload: one thread and one TCP connection per 6-mer prefix
+    (metaenumerate.cpp:268-309), the connections drained by local sinks.  Timed from the first connection to the last close, i.e.
+    without the index load; the node count of those prefixes comes from the GPU run of the same prefixes (outputs are identical)."""
+    import random
+    import socket
+    import subprocess
+    import threading
+    exe = os.path.join(ROOT, "oracle", "_ref", "metaenumerate")
+    if not os.path.exists(exe):
+        return None
+    cores = host_cores()
+    nprefix = max(cores, int(cores * args.cpu_seconds / 1.3))  # about 1.3 core-seconds per 6-mer prefix of this index
+    allp = ["".join(p) for p in itertools.product("ACGT", repeat=6)]
+    random.Random(1).shuffle(allp)
+    prefixes = allp[:min(len(allp), nprefix)]
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(len(prefixes) + 8)
+    port = srv.getsockname()[1]
+    tm = {"first": None, "last": None, "bytes": 0}
+    lock = threading.Lock()
+
+    def drain(c):
+        n = 0
+        while True:
+            b = c.recv(1 << 20)
+            if not b:
+                break
+            n += len(b)
+        c.close()
+        with lock:
+            tm["last"] = time.time()
+            tm["bytes"] += n
+
+    def acceptor():
+        ths = []
+        for _ in prefixes:
+            c, _a = srv.accept()
+            with lock:
+                if tm["first"] is None:
+                    tm["first"] = time.time()
+            t = threading.Thread(target=drain, args=(c,), daemon=True)
+            t.start()
+            ths.append(t)
+        for t in ths:
+            t.join()
+
+    acc = threading.Thread(target=acceptor, daemon=True)
+    acc.start()
+    hostinfo = "".join("127.0.0.1 %d %s\n" % (port, p) for p in prefixes)
+    r = subprocess.run([exe, "--fmin", str(args.fmin), path], input=hostinfo.encode(), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=600)
+    acc.join(timeout=60)
+    srv.close()
+    if r.returncode != 0 or tm["first"] is None:
+        return None
+    dt = tm["last"] - tm["first"]
+    with pydsm.Miner([ix], fmin=args.fmin, stream_mode=True) as m:
+        nodes = sum(m.enumerate(p, discard=True)[1].reported for p in prefixes)
+    return {"value": nodes / dt, "unit": "substrings/s", "cores": cores, "kind": "reference", "host_cpus": os.cpu_count(),
+            "sample": "the unmodified reference metaenumerate (oracle/_ref) on %d random 6-mer prefixes of 4096 of the same index, one thread "
+                      "and one TCP connection per prefix into local sinks, %d nodes (%.0f MB of stream) in %.1f s from first connection to "
+                      "last close; %d of the box's %d CPUs are this job's share" % (len(prefixes), nodes, tm["bytes"] / 1e6, dt, cores, os.cpu_count())}
+
+
+def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
+    """Two more driver-visible measurements of the default N=1 run (each one pass after one warm-up pass, same prefixes):
+    the 64-bit position path on the same index (BASELINE configs[3]'s code path) and eight full-size samples resident on this
+    one GPU with d = 8 (the one-GPU share of configs[2] / [4])."""
+    import torch
+    out = []
+
+    def one(ixs, label, **kw):
+        with pydsm.Miner(ixs, fmin=args.fmin, emax=args.emax, stream=torch.cuda.current_stream().cuda_stream, **kw) as m:
+            m.mine_many(prefixes, text=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = m.mine_many(prefixes, text=False)[1]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        return {"record": label, "value": st.reported / dt, "unit": "substrings/s", "ms_per_step": dt * 1e3, "nodes": st.reported,
+                "tuples": st.tuples, "union_nodes": st.union_nodes, "expand_ms": st.expand_ms, "device_ms": st.device_ms,
+                "splits": st.splits}
+
+    try:
+        out.append(dict(one([ix], "same workload with 64-bit positions (wide=1)", pmin=pmin, wide=1), dtype="u64"))
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "64-bit positions", "error": repr(e)})
+    try:
+        a8 = argparse.Namespace(**vars(args))
+        a8.gpus, a8.nlocal = 1, 8
+        t0 = time.time()
+        paths = [build_index(a8, j, dev)[0] for j in range(8)]
+        build_s = time.time() - t0
+        ixs = [pydsm.Index(pth, device=local) for pth in paths]
+        for pm, px, lab in ((2, 0, "configs[2] share"), (1, 1, "configs[4] share (sample-specific substrings)")):
+            rec = one(ixs, "8 read sets of %d x %d bp resident on one GPU, d=8, pmin=%d pmax=%d: %s" % (args.reads, args.rlen, pm, px, lab),
+                      pmin=pm, pmax=px)
+            rec.update(dtype="u32", index_build_s=build_s)
+            out.append(rec)
+        for x in ixs:
+            x.close()
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "8 samples on one GPU", "error": repr(e)})
+    return out
 
 
 def main():
@@ -353,8 +465,21 @@ def main():
                        "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps)},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
-        if world == 1 and args.nlocal == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(path, args, pmin)
+        default_cfg = world == 1 and args.nlocal == 1 and not args.stream_mode and not forced
+        if default_cfg and not args.no_cpu:
+            ref = None
+            try:
+                ref = cpu_baseline_reference(path, args, ix, pydsm)
+            except Exception as e:  # noqa: BLE001
+                print("bench: reference CPU baseline failed: %r" % (e,), file=sys.stderr, flush=True)
+            port = cpu_baseline(path, args, pmin, seconds=args.cpu_seconds / 2 if ref is not None else None)
+            if ref is not None:
+                ref["port_substrings_per_s"] = port["value"]  # our CPU restatement of the same path, same cores, for comparison
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = port
+        if default_cfg and not args.no_extras and not args.no_cpu and not args.wide and args.reads >= 1_000_000:
+            out["extra_records"] = extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin)
         print(json.dumps(out), flush=True)
     for x in ixs:
         x.close()

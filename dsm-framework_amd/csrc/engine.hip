@@ -2774,7 +2774,7 @@ int dsm_trie_parse(const uint8_t* bytes, size_t n, int device, dsm_trie** out) {
     std::vector<HostTrieLevel> L;
     u64 nodes = 0, mf = 0;
     if (int rc = parse_client_stream(bytes, n, L, &nodes, &mf)) return rc;
-    std::unique_ptr<dsm_trie> t(new dsm_trie());
+    std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);  // error paths release the device arrays too
     t->device = device;
     t->nodes = nodes;
     t->maxfreq = mf;
@@ -2838,19 +2838,26 @@ int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // m
     }
     char* out = (char*)malloc(cap[nth] + 64);
     if (!out) return fail(DSM_E_NOMEM, "malloc failed");
+    std::atomic<int> bad{0};  // a caller-made batch whose numbers do not fit the windows (an entropy of 1e300 prints 300 digits)
     auto work = [&](unsigned t) {
         u64 lo, hi;
         range(t, lo, hi);
         char* o = out + cap[t];
         const size_t room = cap[t + 1] - cap[t] + (t + 1 == nth ? 64 : 0);
         size_t w = 0;
-        for (u64 r = lo; r < hi; ++r) {
+        for (u64 r = lo; r < hi && !bad; ++r) {
             size_t pl = b->path_off[r + 1] - b->path_off[r];
             memcpy(o + w, b->path_bytes + b->path_off[r], pl);
             w += pl;
-            w += (size_t)snprintf(o + w, room - w, " %f", b->entropy[r]);
-            for (u32 q = b->pair_off[r]; q < b->pair_off[r + 1]; ++q)
-                w += (size_t)snprintf(o + w, room - w, " %d:%lu", (int)b->ids[q], (unsigned long)b->freqs[q]);
+            int k = snprintf(o + w, room - w, " %f", b->entropy[r]);
+            if (k < 0 || (size_t)k >= room - w) { bad = 1; break; }
+            w += (size_t)k;
+            for (u32 q = b->pair_off[r]; q < b->pair_off[r + 1] && !bad; ++q) {
+                k = snprintf(o + w, room - w, " %d:%lu", (int)b->ids[q], (unsigned long)b->freqs[q]);
+                if (k < 0 || (size_t)k + 1 >= room - w) { bad = 1; break; }
+                w += (size_t)k;
+            }
+            if (bad) break;
             o[w++] = '\n';
         }
         used[t] = w;
@@ -2861,6 +2868,7 @@ int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // m
         work(0);
         for (auto& x : th) x.join();
     }
+    if (bad) { free(out); return fail(DSM_E_INVAL, "dsm_format_batch: a value does not fit its text window (entropy out of range?)"); }
     size_t w = used[0];
     for (unsigned t = 1; t < nth; ++t) {  // close the gaps between the windows
         memmove(out + w, out + cap[t], used[t]);

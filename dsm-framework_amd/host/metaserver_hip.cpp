@@ -88,21 +88,24 @@ int main(int argc, char** argv) {
     std::string perr;
     std::mutex err_mu;
     size_t pending = d;
+    // An error inside the accept loop ends the process the way the reference's exit(1) does; reader threads of earlier
+    // connections may still be running, and returning from main with joinable threads would abort instead.
+    auto fatal = [] { std::cerr.flush(); _exit(1); };
     while (pending) {  // metaserver.cpp:682-728: handshake 'S' name '.', then the node stream until EOF
         int fd = accept(sock, nullptr, nullptr);
-        if (fd < 0) { std::cerr << "ERROR on accept" << std::endl; return 1; }
+        if (fd < 0) { std::cerr << "ERROR on accept" << std::endl; fatal(); }
         uint8_t ch = 0;
-        if (recv(fd, &ch, 1, MSG_WAITALL) != 1 || ch != 'S') { std::cerr << "received invalid start byte: " << (int)ch << std::endl; return 1; }
+        if (recv(fd, &ch, 1, MSG_WAITALL) != 1 || ch != 'S') { std::cerr << "received invalid start byte: " << (int)ch << std::endl; fatal(); }
         std::string name;
         for (;;) {
-            if (recv(fd, &ch, 1, MSG_WAITALL) != 1) { std::cerr << "connection closed inside the handshake" << std::endl; return 1; }
+            if (recv(fd, &ch, 1, MSG_WAITALL) != 1) { std::cerr << "connection closed inside the handshake" << std::endl; fatal(); }
             if (ch == '.') break;
             name += (char)ch;
         }
         auto f = libtoid.find(name);
-        if (f == libtoid.end()) { std::cerr << "received invalid libname: \"" << name << "\"" << std::endl; return 1; }
+        if (f == libtoid.end()) { std::cerr << "received invalid libname: \"" << name << "\"" << std::endl; fatal(); }
         const int id = f->second;
-        if (seen[id]) { std::cerr << "DUPLICATE CONNECTING CLIENT! id = " << id << ", name = " << name << std::endl; return 1; }
+        if (seen[id]) { std::cerr << "DUPLICATE CONNECTING CLIENT! id = " << id << ", name = " << name << std::endl; fatal(); }
         seen[id] = true;
         --pending;
         if (verbose) std::cerr << "new connection id = " << id << ", name = " << name << " (" << pending << " pending)" << std::endl;

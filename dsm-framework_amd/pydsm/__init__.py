@@ -199,13 +199,19 @@ class Index:
         """Wire bytes of one client connection: b'S' name b'.' + node grammar (EnumerateQuery.cpp).  -> (bytes, stats)"""
         chunks = []
 
+        err = []
+
         def sink(ctx, p, n):
-            chunks.append(C.string_at(p, n))
-            return 0
+            try:
+                chunks.append(C.string_at(p, n))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return 1
 
         cb = BYTE_SINK(sink)
         st = Stats()
-        _check(lib().dsm_enumerate(self.h, prefix.encode(), fmin, maxdepth, cb, None, C.byref(st)))
+        _check_sink(lib().dsm_enumerate(self.h, prefix.encode(), fmin, maxdepth, cb, None, C.byref(st)), err)
         body = b"".join(chunks)
         if with_header:
             body = b"S" + self.name.encode() + b"." + body  # metaenumerate.cpp:285-286
@@ -245,19 +251,31 @@ def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, r
     return p
 
 
-def _tuple_sink(out, text, on_batch):
+def _tuple_sink(out, text, on_batch, err):
+    """err: a list that receives the exception a callback raised.  An exception must not unwind through C (ctypes would print
+    it and report success): the sink returns 1 instead, the library fails with DSM_E_SINK and the caller re-raises."""
     def sink(ctx, b):
-        if on_batch is not None:
-            on_batch(b.contents)
-        if text:
-            t = C.c_void_p()
-            n = C.c_size_t(0)
-            if lib().dsm_format_batch(b, C.byref(t), C.byref(n)) != 0:
-                return 1
-            out.append(C.string_at(t, n.value))
-            lib().dsm_free(t)
-        return 0
+        try:
+            if on_batch is not None:
+                on_batch(b.contents)
+            if text:
+                t = C.c_void_p()
+                n = C.c_size_t(0)
+                if lib().dsm_format_batch(b, C.byref(t), C.byref(n)) != 0:
+                    return 1
+                out.append(C.string_at(t, n.value))
+                lib().dsm_free(t)
+            return 0
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            return 1
     return TUPLE_SINK(sink)
+
+
+def _check_sink(rc, err):
+    if err:
+        raise err[0]
+    _check(rc)
 
 
 class Miner:
@@ -277,34 +295,40 @@ class Miner:
         _check(lib().dsm_miner_create(hs, len(indexes), C.byref(p), 1 if stream_mode else 0, C.byref(self.h)))
 
     def mine(self, prefix, text=True, on_batch=None):
-        out = []
-        cb = _tuple_sink(out, text, on_batch)
+        out, err = [], []
+        cb = _tuple_sink(out, text, on_batch, err)
         st = Stats()
-        _check(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)))
+        _check_sink(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)), err)
         return (b"".join(out) if text else None), st
 
     def mine_many(self, prefixes, text=True, on_batch=None):
         """All prefixes in one call (host emission of prefix k overlaps GPU work on prefix k+1)."""
-        out = []
-        cb = _tuple_sink(out, text, on_batch)
+        out, err = [], []
+        cb = _tuple_sink(out, text, on_batch, err)
         st = Stats()
         arr = (C.c_char_p * len(prefixes))(*[p.encode() for p in prefixes])
-        _check(lib().dsm_miner_mine_many(self.h, arr, len(prefixes), cb, None, C.byref(st)))
+        _check_sink(lib().dsm_miner_mine_many(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
         return (b"".join(out) if text else None), st
 
     def enumerate(self, prefix, with_header=True, discard=False):
         chunks = []
         nbytes = [0]
 
+        err = []
+
         def sink(ctx, p, n):
-            nbytes[0] += n
-            if not discard:
-                chunks.append(C.string_at(p, n))
-            return 0
+            try:
+                nbytes[0] += n
+                if not discard:
+                    chunks.append(C.string_at(p, n))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return 1
 
         cb = BYTE_SINK(sink)
         st = Stats()
-        _check(lib().dsm_miner_enumerate(self.h, prefix.encode(), cb, None, C.byref(st)))
+        _check_sink(lib().dsm_miner_enumerate(self.h, prefix.encode(), cb, None, C.byref(st)), err)
         if discard:
             return nbytes[0], st
         body = b"".join(chunks)
@@ -336,11 +360,11 @@ def mine(indexes, prefix, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, minde
     p = _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes, wide,
                      stream, keep)
     p.prefix = prefix.encode()
-    out = []
-    cb = _tuple_sink(out, text, on_batch)
+    out, err = [], []
+    cb = _tuple_sink(out, text, on_batch, err)
     hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
     st = Stats()
-    _check(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)))
+    _check_sink(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)), err)
     return (b"".join(out) if text else None), st
 
 
@@ -369,11 +393,11 @@ def merge(tries, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0,
     """metaserver's traverse() over parsed client streams; tries[k] is sample id k.  -> (tuple text, Stats)"""
     keep = []
     p = _make_params(0, MAXDEPTH_NONE, pmin, pmax, mindepth, emin, emax, 1, 0, None, None, arena_bytes, 0, None, keep)
-    out = []
-    cb = _tuple_sink(out, text, on_batch)
+    out, err = [], []
+    cb = _tuple_sink(out, text, on_batch, err)
     hs = (C.c_void_p * len(tries))(*[t.h for t in tries])
     st = Stats()
-    _check(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)))
+    _check_sink(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)), err)
     return (b"".join(out) if text else None), st
 
 

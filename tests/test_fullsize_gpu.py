@@ -225,3 +225,75 @@ def test_two_full_size_samples_against_oracle(big):
     want, ost = orc.mine([o0, o1], names, ["G"], fmin=10, maxdepth=11, pmin=1, emax=2.0, threads=8)
     assert got == want and st.tuples == ost[4] and st.max_frontier > 1000000
     ix1.close(); o0.close(); o1.close()
+
+
+def test_eight_full_size_samples_on_one_card(big):
+    """The one-GPU share of BASELINE configs[2], [3] and [4]: eight 10^7-read samples (seeds 42..49, 5 % private sequence
+    each, n = 2.02e9 per index) resident on one card, d = 8, with the three configurations' filters -- the reference default
+    (-P 2), -P 2 --pmax 8 with 64-bit positions, and -P 1 --pmax 1 (sample-specific substrings; no reader-set order needed)
+    -- on random 8-mers and on a one-letter prefix cut at depth 10: tuples and counters equal the oracle's.  Then configs[4]'s
+    residency cycle with two groups of eight handles: one group is offloaded while the other mines, and comes back by an
+    asynchronous copy on a side stream (metaserver.cpp:406-419 for the predicates)."""
+    import torch
+    import orc
+    from pydsm import builder
+    pydsm, ix0, path0, reads = big
+    d = os.path.dirname(path0)
+    paths = []
+    for s in range(8):
+        p = os.path.join(d, "sample-%d.s%d_r%d_l100_g%d_e0.005_p0.05.fmi" % (s, 42 + s, reads, reads * 5))
+        if not os.path.exists(p):
+            codes = builder.synth_reads(42 + s, reads, 100, reads * 5, 0.005, device="cuda", private_frac=0.05)
+            builder.build_from_codes(codes, p + ".tmp")
+            del codes
+            torch.cuda.empty_cache()
+            os.replace(p + ".tmp", p)
+        paths.append(p)
+    torch.cuda.empty_cache()
+    A = [pydsm.Index(p) for p in paths]
+    O = [orc.Index(p) for p in paths]
+    names = [ix.name for ix in A]
+    assert len(set(names)) == 8 and all(ix.n == reads * 202 for ix in A)
+    rng = np.random.default_rng(2027)
+    kmers = ["".join(rng.choice(list("ACGT"), 8)) for _ in range(3)]
+    cfgs = [dict(fmin=10, pmin=2, emax=2.0), dict(fmin=10, pmin=2, pmax=8, emax=2.0, wide=1), dict(fmin=10, pmin=1, pmax=1, emax=2.0)]
+    first = {}
+    for kw in cfgs:
+        okw = {k: v for k, v in kw.items() if k != "wide"}
+        with pydsm.Miner(A, **kw) as m:
+            for p in kmers:
+                got, st = m.mine(p)
+                want, ost = orc.mine(O, names, [p], threads=8, **okw)
+                assert got == want, (p, kw)
+                assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (p, kw)
+                first.setdefault((p, kw.get("pmax", 0)), got)
+        got, st = pydsm.mine(A, "C", maxdepth=10, **kw)
+        want, ost = orc.mine(O, names, ["C"], maxdepth=10, threads=8, **okw)
+        assert got == want and (st.reported, st.union_nodes, st.tuples, st.pairs) == (ost[0], ost[3], ost[4], ost[5]), kw
+        assert st.max_frontier > 200000 and st.pair_order_exact == 1
+    for o in O:
+        o.close()
+    # ---- two groups of eight: B is a second set of handles on the same files
+    B = [pydsm.Index(p) for p in paths]
+    kw = cfgs[2]
+    p = kmers[0]
+    for ix in A:
+        ix.offload()
+    assert not any(ix.resident for ix in A)
+    with pytest.raises(pydsm.DsmError):
+        pydsm.mine(A, p, **kw)                      # an offloaded group is refused, not read
+    side = torch.cuda.Stream()
+    with pydsm.Miner(B, **kw) as mb:
+        for ix in A:                                # group A comes back on the side stream while group B mines
+            ix.reload(side.cuda_stream)
+        got, _ = mb.mine(p)
+        assert got == first[(p, 1)]
+    side.synchronize()
+    for ix in B:
+        ix.offload()
+    assert all(ix.resident for ix in A) and not any(ix.resident for ix in B)
+    got, _ = pydsm.mine(A, p, **kw)
+    assert got == first[(p, 1)]
+    assert A[3].check() == A[3].n
+    for ix in A + B:
+        ix.close()
