@@ -57,6 +57,49 @@ def test_dsm_node_device_list_runs_the_exchange_on_rccl(golden, tmp_path):
     assert r.returncode == 1 and b"multiple of the number of devices" in r.stderr
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "metaenumerate_patched")), reason="oracle/_ref/metaenumerate_patched not present")
+def test_patched_reference_client_sends_the_reference_streams(golden):
+    """INTEGRATION.md section 2, compiled: the reference metaenumerate with its EnumerateQuery::enumerate call replaced by
+    dsm_enumerate (oracle/integration_s2.patch, built by oracle/Makefile.ref) sends, prefix by prefix, exactly the bytes the
+    unmodified client sends (the committed golden streams)."""
+    import threading
+    names = golden.manifest["sets"]["toy3"]["names"]
+    prefixes = ["A", "C", "G", "T"]
+    for name in names[:2]:
+        got = {}
+        socks = []
+        hosts = ""
+        for p in prefixes:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            s.listen(1)
+            socks.append((p, s))
+            hosts += "127.0.0.1 %d %s\n" % (s.getsockname()[1], p)
+
+        def serve(p, s):
+            c, _ = s.accept()
+            buf = b""
+            while True:
+                b = c.recv(1 << 16)
+                if not b:
+                    break
+                buf += b
+            c.close()
+            s.close()
+            got[p] = buf
+
+        ths = [threading.Thread(target=serve, args=ps) for ps in socks]
+        for t in ths:
+            t.start()
+        r = subprocess.run([os.path.join(REF, "metaenumerate_patched"), "--fmin", "2", golden.fmi("toy3", name)], input=hosts.encode(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        for t in ths:
+            t.join(timeout=60)
+        assert r.returncode == 0, r.stderr
+        for p in prefixes:
+            assert got[p] == golden.stream("toy3", name, p), (name, p)
+
+
 def test_check_mode(golden):
     r = subprocess.run([os.path.join(HOST, "metaenumerate_hip"), "--check", golden.fmi("toy3", "toy-1")], input=b"localhost 5000 A\n",
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
