@@ -1224,12 +1224,20 @@ __global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ pat
 __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const LevelDev* __restrict__ lv, const u32* __restrict__ path_off,
                                                          const u32* __restrict__ pair_off, char* __restrict__ paths, u32* __restrict__ ids,
                                                          u64* __restrict__ freqs) {
+    // the per-level link arrays and candidate bases are read at every step of every walk: kept in LDS (a step is then ONE dependent
+    // global load, the link itself)
+    constexpr u32 LDS_LEVELS = 1024;
+    __shared__ const u32* s_slot[LDS_LEVELS];
+    __shared__ u32 s_cbase[LDS_LEVELS];
+    const u32 nl = nlev < LDS_LEVELS ? nlev : LDS_LEVELS;
+    for (u32 q = threadIdx.x; q < nl; q += blockDim.x) { s_slot[q] = lv[q].slot; s_cbase[q] = lv[q].cbase; }
+    __syncthreads();
     const u32 f = blockIdx.x * blockDim.x + threadIdx.x;  // candidates in level-major order
     if (f >= nt) return;
     u32 lo = 1, hi = nlev - 1;  // the level whose candidates include f: largest l with cbase[l] <= f among the levels that have any
     while (lo < hi) {
         const u32 mid = (lo + hi + 1) >> 1;
-        if (lv[mid].cbase <= f) lo = mid; else hi = mid - 1;
+        if ((mid < LDS_LEVELS ? s_cbase[mid] : lv[mid].cbase) <= f) lo = mid; else hi = mid - 1;
     }
     const u32 lvl = lo;
     const LevelDev L = lv[lvl];
@@ -1243,7 +1251,7 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
     char* dst = paths + path_off[r];
     u32 word = 0, have = 0;
     for (u32 l = lvl; l >= 1; --l) {
-        const u32 sl = lv[l].slot[v];
+        const u32 sl = (l < LDS_LEVELS ? s_slot[l] : lv[l].slot)[v];
         word = (word << 8) | ((0x54474341u >> (8 * (sl & 3))) & 0xFFu);  // "ACGT"[sym]: the lowest character so far goes to the lowest byte
         v = sl >> 2;
         if (++have == 4) {
