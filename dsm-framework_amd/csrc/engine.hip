@@ -205,7 +205,16 @@ struct ExpandArgs {
     SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_pack;  // BitRank::rank calls of getL by 3-bit code, four bits each (a table in the argument block would be a load)
+    u64 costsum_lo, costsum_hi;  // sum of cost[c] over the bases of a 4-bit set, six bits per set: sets 0-9, sets 10-15
 };
+
+__device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
+    return (u32)((set < 10 ? a.costsum_lo >> (6 * set) : a.costsum_hi >> (6 * (set - 10))) & 63u);
+}
+// the set bits of a 4-bit mask in increasing order, two bits each (masks 0-7 in LO, 8-15 in HI, eight bits per mask)
+__device__ __forceinline__ u32 bit_list(u32 m) {
+    return (u32)(((m & 8u) ? 0xe439380e340d0c03ull : 0x2409080204010000ull) >> (8 * (m & 7u))) & 0xFFu;
+}
 
 template <typename P> struct Vec4;
 template <> struct Vec4<u32> { typedef uint4 type; };
@@ -345,9 +354,11 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         // ---- the distinct blocks of the tile (see the staging note above) ----
         u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
         u32 pm = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane; running maximum over the lanes below = the last block listed
+        if (!__all(live)) {  // absent nodes in between (several samples, or the last tile): the maximum is carried across them
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
-        u32 prev = __shfl_up(pm, 1, 64);
+            for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
+        }
+        u32 prev = __shfl_up(pm, 1, 64);  // (every lane present: the blocks increase along the lanes, the lane below holds the maximum)
         if (lane == 0) prev = 0;
         const bool f0 = live && (u32)b0 + 1u > prev, f1 = live && b1 != b0;
         const u64 m0 = __ballot(f0), m1 = __ballot(f1);
@@ -397,20 +408,30 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         staged_blk(wl, idx1, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
         const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
-        if (single && a.allowed) n_rank += (a.access_pack >> (4 * lcode)) & 15u;
+        u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if ((a.allowed >> c) & 1u) {
                 const P nsp = Rsp[c], nep = Rep[c] - 1;
-                const bool nonempty = nsp <= nep;
-                if (!single) { n_lf += 2; n_rank += 2 * a.cost[c]; }  // Query::pushChar, Query.h:37-45
-                if (nonempty) {
-                    if (!single || lcode == (u32)c) { n_lf += 2 * ne + (single ? 2 : 0); n_rank += (2 * ne + (single ? 2 : 0)) * a.cost[c]; }
+                if (nsp <= nep) {
+                    nonempty |= 1u << c;
                     if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
                         present |= 1u << c;
                         if ((u64)(nep - nsp) + 1 >= 65535) acc.wide = true;
                     }
                 }
+            }
+        }
+        // What the reference would have spent on this node: two LF per attempted base (Query::pushChar, Query.h:37-45) and two per
+        // left-extension interval for every base whose interval is non-empty; BitRank::rank calls = LF calls weighted by the
+        // base's code length (a.costsum: the sums per set of bases, six bits each).
+        n_lf = 2 * (u32)__popc(a.allowed) + 2 * ne * (u32)__popc(nonempty);
+        n_rank = 2 * costsum(a, a.allowed) + 2 * ne * costsum(a, nonempty);
+        if (__any(single)) {  // nodes of frequency 1 follow one branch by getL instead (only reachable with fmin = 1)
+            if (single) {
+                const bool go = a.allowed && ((nonempty >> lcode) & 1u) && lcode < 4;
+                n_lf = go ? 2 * ne + 2 : 0u;
+                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * DSM_PICK(a.cost, lcode) : 0u);
             }
         }
         if (!live) { n_lf = 0; n_rank = 0; present = 0; }
@@ -447,15 +468,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     {
         const u32 ne1 = ne ? ne : 1u;
         const u32 npair = k * ne1;
-        u32 cjpack = 0, kkpack = 0;  // two bits per slot: bases of the children / of the intervals, in order
-        {
-            u32 m = present, mm = emask;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cjpack |= (m ? (u32)__ffs(m) - 1u : 0u) << (2 * q); m &= m - 1;
-                kkpack |= (mm ? (u32)__ffs(mm) - 1u : 0u) << (2 * q); mm &= mm - 1;
-            }
-        }
+        const u32 cjpack = bit_list(present), kkpack = bit_list(emask);  // two bits per slot: bases of the children / of the intervals, in order
         u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
         P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
         P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
@@ -524,8 +537,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
 }
 
+// (32-bit positions fit four waves per SIMD without spilling when the allocator is told to aim for it; 64-bit positions take three)
 template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(256) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) == 4 ? 4 : 3))) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
                                                      u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                                      u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
                                                      unsigned long long* __restrict__ childmax) {
@@ -2138,6 +2152,13 @@ class Engine {
                 for (int c = 0; c < 4; ++c) ea.cost[c] = m.lfcost[c];
                 const bool one_sb = (m.n >> SB_SHIFT) == 0;
                 for (int c = 0; c < 4; ++c) ea.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
+                ea.costsum_lo = ea.costsum_hi = 0;
+                for (u32 set = 0; set < 16; ++set) {
+                    u64 sum = 0;
+                    for (int c = 0; c < 4; ++c) sum += ((set >> c) & 1u) ? m.lfcost[c] : 0u;
+                    if (sum > 63) return fail(DSM_E_UNSUPPORTED, "Huffman codes too long for the cost table");
+                    if (set < 10) ea.costsum_lo |= sum << (6 * set); else ea.costsum_hi |= sum << (6 * (set - 10));
+                }
                 ea.access_pack = 0;
                 for (int c = 0; c < 8; ++c) {
                     const u32 bits = c < m.ncodes ? m.codes[m.code2byte[c]].bits : 0;
