@@ -103,9 +103,30 @@ def synth_reads(seed, nreads, rlen, genome_len, sub_rate=0.005, device="cpu", pr
 # ------------------------------------------------------------------------------------------------
 # BWT of a string collection by prefix doubling
 # ------------------------------------------------------------------------------------------------
-def bwt_collection(sym, starts=None, width=None):
+def bwt_collection_hip(sym):
+    """The same BWT from libdsmhip's dsm_bwt_build (csrc/bwt.hip: bounded-depth radix sort of the suffixes on the GPU, no
+    2^31 limit).  sym: flat uint8 CUDA tensor whose 0 bytes are exactly the terminators."""
+    import ctypes as C
+    from . import lib, _check
+    L = lib()
+    L.dsm_bwt_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    L.dsm_bwt_build.restype = C.c_int
+    sym = sym.contiguous()
+    bwt = torch.empty_like(sym)
+    torch.cuda.synchronize(sym.device)
+    _check(L.dsm_bwt_build(sym.data_ptr(), sym.numel(), bwt.data_ptr(), sym.device.index or 0, None))
+    return bwt
+
+
+def bwt_collection(sym, starts=None, width=None, hip=None):
     """sym: flat uint8 tensor, every text ends with 0.  Either `starts` (int64 [R+1], variable length texts)
-    or `width` (equal-length texts).  Terminators sort by text order.  Returns the BWT (uint8 tensor)."""
+    or `width` (equal-length texts).  Terminators sort by text order.  Returns the BWT (uint8 tensor).
+    hip: use the library's GPU suffix sort (default: whenever sym lives on the GPU); False = the torch prefix doubling below,
+    which also runs on the CPU (n < 2^31)."""
+    if hip is None:
+        hip = sym.is_cuda
+    if hip:
+        return bwt_collection_hip(sym)
     dev = sym.device
     n = sym.numel()
     pos = torch.arange(n, device=dev, dtype=torch.int64)

@@ -218,6 +218,16 @@ int dsm_format_batch(const dsm_tuple_batch* batch, char** text, size_t* len);
 void dsm_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------
+ * Index construction: the multi-string BWT the reference builder computes with incbwt
+ * (builder.cpp:183-285, TextCollectionBuilder.cpp:65-152, incbwt/rlcsa_builder.cpp:35-78,165-179).  d_text: n bytes on the
+ * device, the strings one after the other, each ending in a 0 byte; string k's terminator sorts as $_k with
+ * $_0 < $_1 < ... < every other byte (incbwt/misc/utils.cpp:362-367).  d_bwt receives the n BWT bytes (0 where the suffix
+ * starts a string).  At most 15 distinct non-zero bytes.  Sized for n beyond 2^32 (bounded-depth radix sort in batches).
+ * pydsm.builder writes the .fmi v17 file from it (Huffman tree and serialisation identical to the reference's).
+ * ---------------------------------------------------------------------------------------------- */
+int dsm_bwt_build(const uint8_t* d_text, uint64_t n, uint8_t* d_bwt, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Distance matrices of the tuple stream: the accumulation of wrapper-distance-matrix/smtxt2entropy.c
  * on the GPU.
  *   per tuple: normalised entropy (smtxt2entropy.c:128-145, evaluated on the host with the reference's expression

@@ -94,3 +94,50 @@ def test_reference_client_reads_our_file(golden, builder, tmp_path):
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     t.join()
     assert got[0] == golden.stream("toy3", name, "GT")
+
+
+# ---- the GPU suffix sort of the writer (csrc/bwt.hip, dsm_bwt_build) ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname,name", [("toy3", "toy-1"), ("toyN", "toyN"), ("five", "five-4")])
+def test_hip_bwt_writes_the_reference_builders_file(golden, builder, tmp_path, setname, name):
+    out = str(tmp_path / (name + ".fasta.fmi"))
+    builder.build_from_fasta(golden.fasta(setname, name), out, device="cuda")
+    assert open(out, "rb").read() == open(golden.fmi(setname, name), "rb").read()
+
+
+@pytest.mark.gpu
+def test_hip_bwt_equals_prefix_doubling_on_awkward_collections(builder, monkeypatch):
+    """Variable lengths, duplicate strings (ties resolved by text order), homopolymers, strings that are suffixes of others, N and
+    '-' symbols, single-symbol strings; also with tiny batches so that every bucket boundary is crossed."""
+    rng = np.random.default_rng(5)
+    reads = ["A", "T", "ACGT", "ACGT", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", "TTTT", "NNNN", "ACGTNACGT",
+             "GATTACA" * 9, "GATTACA" * 9 + "G", "C" * 70, "C" * 71]
+    for _ in range(400):
+        ln = int(rng.integers(1, 120))
+        reads.append("".join(rng.choice(list("ACGT"), ln)))
+    for _ in range(60):
+        reads.append(reads[int(rng.integers(0, len(reads)))])  # exact duplicates
+    sym, starts = builder.texts_from_reads(reads)
+    want = builder.bwt_collection(torch.from_numpy(sym), starts=torch.from_numpy(starts), hip=False)
+    for batch in (None, "1000", "37"):
+        if batch is None:
+            monkeypatch.delenv("DSM_BWT_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("DSM_BWT_BATCH", batch)
+        got = builder.bwt_collection(torch.from_numpy(sym).cuda(), hip=True)
+        assert torch.equal(got.cpu(), want), batch
+
+
+@pytest.mark.gpu
+def test_hip_bwt_equals_prefix_doubling_on_a_read_set(builder):
+    codes = builder.synth_reads(seed=11, nreads=200000, rlen=100, genome_len=500000, sub_rate=0.005, device="cuda", private_frac=0.05)
+    sym = builder.texts_from_codes(codes)
+    want = builder.bwt_collection(sym, width=202, hip=False)
+    got = builder.bwt_collection(sym, hip=True)
+    assert torch.equal(got, want)
+    # many small batches give the same order
+    os.environ["DSM_BWT_BATCH"] = "3000000"
+    try:
+        assert torch.equal(builder.bwt_collection(sym, hip=True), want)
+    finally:
+        del os.environ["DSM_BWT_BATCH"]
