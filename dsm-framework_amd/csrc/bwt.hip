@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void collect_write_kernel(const u8* __restrict
         if (ks[j] != 0xFFFFFFFFu) {
             const u64 p = base + j;
             pos[o] = p;
-            key[o] = ((u64)ks[j] << 48) | pack_digits(t, n, tab, p + 3, 12);  // the first 15 symbols
+            key[o] = pack_digits(t, n, tab, p, 15);  // the first 15 symbols (in one go: a terminator among the first three ends the key)
             ++o;
         }
     }

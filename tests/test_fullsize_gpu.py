@@ -297,3 +297,74 @@ def test_eight_full_size_samples_on_one_card(big):
     assert A[3].check() == A[3].n
     for ix in A + B:
         ix.close()
+
+
+def test_real_bwt_beyond_2_32():
+    """A REAL index beyond 2^32 symbols (BASELINE configs[3]'s regime; round 1 could only fake one): 2.15e7 reads of 100 bp
+    (n = 4.343e9) are suffix-sorted on the GPU by dsm_bwt_build (csrc/bwt.hip), written as .fmi v17, opened with 64-bit
+    positions and three superblocks, and must pass --check and answer LF, tuples and counters exactly like the oracle on the
+    same file.  DSM_BIGBWT_READS=40000000 builds configs[3]'s full 4-Gbase sample (n = 8.08e9)."""
+    import time
+    import torch
+    import orc
+    import pydsm
+    from pydsm import builder
+    reads = int(os.environ.get("DSM_BIGBWT_READS", "21500000"))
+    d = os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "real-%d.fmi" % reads)
+    if not os.path.exists(path):
+        t0 = time.time()
+        codes = builder.synth_reads(4242, reads, 100, reads * 5, 0.005, device="cuda")
+        sym = builder.texts_from_codes(codes)
+        del codes
+        torch.cuda.empty_cache()
+        t1 = time.time()
+        bwt = builder.bwt_collection(sym, hip=True)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        del sym
+        torch.cuda.empty_cache()
+        builder.write_fmi(bwt, path + ".tmp", reads, 202)
+        del bwt
+        torch.cuda.empty_cache()
+        os.replace(path + ".tmp", path)
+        print("reads %.1f s, BWT of n = %d: %.1f s (%.1f Msymbols/s), .fmi %.1f s" % (t1 - t0, reads * 202, t2 - t1, reads * 202 / (t2 - t1) / 1e6,
+                                                                                    time.time() - t2))
+    n = reads * 202
+    assert n > (1 << 32)
+    o = orc.Index(path)
+    with pydsm.Index(path) as ix:
+        assert ix.n == o.n == n
+        assert ix.check() == n                      # the LF intervals of all symbols tile [0, n): the BWT is a permutation-consistent one
+        rng = np.random.default_rng(123)
+        Cc, cnt, bits, code = o.meta()
+        syms = [int(s) for s in np.nonzero(cnt)[0]]
+        assert cnt[0] == reads and cnt[ord("-")] == reads and cnt[ord("A")] + cnt[ord("C")] + cnt[ord("G")] + cnt[ord("T")] == reads * 200
+        pos = np.concatenate([np.array([0xFFFFFFFFFFFFFFFF, 0, n - 1, (1 << 32) - 1, 1 << 32, (1 << 32) + 1], np.uint64),
+                              rng.integers(0, n, 200000).astype(np.uint64)])
+        cs = rng.choice(syms, len(pos)).astype(np.uint8)
+        assert (ix.lf_batch(cs, pos) == o.lf_batch(cs, pos)).all()
+        with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m, pydsm.Miner([ix], fmin=10, stream_mode=True) as sm:
+            for _ in range(4):
+                p = "".join(rng.choice(list("ACGT"), 8))
+                got, st = m.mine(p)
+                want, ost = orc.mine([o], [ix.name], [p], fmin=10, pmin=1, emax=2.0)
+                assert got == want, p
+                assert st.reported > 1000 and (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples) == ost[:5], p
+                wire, sst = sm.enumerate(p)
+                owire, _ = o.enumerate(ix.name, p, fmin=10)
+                assert wire == owire, p
+        # a real BWT, unlike the pseudo one: every read's reverse complement is in the collection, so a k-mer and its reverse
+        # complement have the same frequency -- check it through LF-interval sizes of a few random 12-mers
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        with pydsm.Miner([ix], fmin=1, maxdepth=12, pmin=1, emax=0.0) as m1:
+            for _ in range(3):
+                p = "".join(rng.choice(list("ACGT"), 12))
+                rc = "".join(comp[c] for c in reversed(p))
+                a, _ = m1.mine(p)
+                b, _ = m1.mine(rc)
+                fa = [ln.split()[-1].split(":")[1] for ln in a.decode().splitlines() if ln.split()[0] == p]
+                fb = [ln.split()[-1].split(":")[1] for ln in b.decode().splitlines() if ln.split()[0] == rc]
+                assert fa == fb, (p, rc, fa, fb)
+    o.close()
