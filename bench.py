@@ -219,6 +219,25 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
             x.close()
     except Exception as e:  # noqa: BLE001
         out.append({"record": "8 samples on one GPU", "error": repr(e)})
+    try:  # BASELINE configs[3]'s sample size: one 4-Gbase read set (n = 8.08e9 > 2^32), a real BWT built here by dsm_bwt_build
+        from pydsm import builder
+        big = 4 * args.reads
+        pth = os.path.join(args.workdir, "sample-4g.s4242_r%d_l%d_g%d.fmi" % (big, args.rlen, 4 * args.genome))
+        t0 = time.time()
+        if not os.path.exists(pth):
+            codes = builder.synth_reads(4242, big, args.rlen, 4 * args.genome, args.sub_rate, device=dev)
+            builder.build_from_codes(codes, pth + ".tmp")
+            del codes
+            torch.cuda.empty_cache()
+            os.replace(pth + ".tmp", pth)
+        build_s = time.time() - t0
+        with pydsm.Index(pth, device=local) as big_ix:
+            rec = one([big_ix], "1 read set of %d x %d bp (n=%d > 2^32, 64-bit positions), configs[3]'s sample size, pmin=1" % (big, args.rlen, big_ix.n),
+                      pmin=1)
+            rec.update(dtype="u64", index_build_s=build_s)
+            out.append(rec)
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "4-Gbase sample", "error": repr(e)})
     return out
 
 

@@ -300,16 +300,17 @@ def test_eight_full_size_samples_on_one_card(big):
 
 
 def test_real_bwt_beyond_2_32():
-    """A REAL index beyond 2^32 symbols (BASELINE configs[3]'s regime; round 1 could only fake one): 2.15e7 reads of 100 bp
-    (n = 4.343e9) are suffix-sorted on the GPU by dsm_bwt_build (csrc/bwt.hip), written as .fmi v17, opened with 64-bit
-    positions and three superblocks, and must pass --check and answer LF, tuples and counters exactly like the oracle on the
-    same file.  DSM_BIGBWT_READS=40000000 builds configs[3]'s full 4-Gbase sample (n = 8.08e9)."""
+    """REAL indexes at BASELINE configs[3]'s size (round 1 could only fake one): 4e7 reads of 100 bp = 4 Gbases per sample
+    (n = 8.08e9 > 2^32) are suffix-sorted on the GPU by dsm_bwt_build (csrc/bwt.hip), written as .fmi v17, opened with 64-bit
+    positions and four superblocks, and must pass --check and answer LF, tuples, counters and wire bytes exactly like the
+    oracle on the same file; then two such samples with configs[3]'s filter (-P 2 --pmax 8).  DSM_BIGBWT_READS shrinks it
+    (n must stay above 2^32: at least 21300000)."""
     import time
     import torch
     import orc
     import pydsm
     from pydsm import builder
-    reads = int(os.environ.get("DSM_BIGBWT_READS", "21500000"))
+    reads = int(os.environ.get("DSM_BIGBWT_READS", "40000000"))
     d = os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "real-%d.fmi" % reads)
@@ -367,4 +368,24 @@ def test_real_bwt_beyond_2_32():
                 fa = [ln.split()[-1].split(":")[1] for ln in a.decode().splitlines() if ln.split()[0] == p]
                 fb = [ln.split()[-1].split(":")[1] for ln in b.decode().splitlines() if ln.split()[0] == rc]
                 assert fa == fb, (p, rc, fa, fb)
+    # ---- a second 4-Gbase sample (5 % private sequence) and configs[3]'s filter with d = 2 ----
+    path2 = os.path.join(d, "real-%d-b.fmi" % reads)
+    if not os.path.exists(path2):
+        codes = builder.synth_reads(4243, reads, 100, reads * 5, 0.005, device="cuda", private_frac=0.05)  # same genome as the first sample
+        builder.build_from_codes(codes, path2 + ".tmp")
+        del codes
+        torch.cuda.empty_cache()
+        os.replace(path2 + ".tmp", path2)
+    o2 = orc.Index(path2)
+    with pydsm.Index(path) as ixa, pydsm.Index(path2) as ixb:
+        names = [ixa.name, ixb.name]
+        assert names[0] != names[1]
+        with pydsm.Miner([ixa, ixb], fmin=10, pmin=2, pmax=8, emax=2.0) as m:
+            for _ in range(3):
+                p = "".join(rng.choice(list("ACGT"), 8))
+                got, st = m.mine(p)
+                want, ost = orc.mine([o, o2], names, [p], fmin=10, pmin=2, pmax=8, emax=2.0, threads=4)
+                assert got == want, p
+                assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, p
+    o2.close()
     o.close()
