@@ -679,6 +679,49 @@ __global__ __launch_bounds__(256) void advance_reduce_kernel(Xchg x, u16* __rest
     if (threadIdx.x < 4) cnt4[(size_t)threadIdx.x * nbp + blockIdx.x] = wtot[0][threadIdx.x] + wtot[1][threadIdx.x] + wtot[2][threadIdx.x] + wtot[3][threadIdx.x];
 }
 
+struct FilterArgs {
+    u32 F;
+    u32 depth;
+    u32 d;
+    u32 pmin, pmax, mindepth;
+    double emin, emax;
+    u32 exact_order;  // 0: d == 1; 1: nibble-packed order[] (d <= 13); 2: u16 order arrays (d > 13)
+};
+
+// output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
+// within ENT_MARGIN of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
+// The device value uses the hardware log2 (v_log_f32, 1 ulp: at most 2^-18 absolute for arguments below 2^64), so it
+// is off by less than 1e-5; the margin leaves a factor of ten.
+constexpr double ENT_MARGIN = 1e-4;
+
+// the output predicates of one node (metaserver.cpp:406-419) given its number of readers t, of children nc and whether its single
+// child carries every reader; merged left char (metaserver.cpp:383-387) and entropy over the samples that hold the node
+template <typename P>
+__device__ __forceinline__ bool filter_node(const FilterArgs& a, const Xchg& x, u32 v, u32 t, u32 nc, u32 same) {
+    if (a.depth < a.mindepth) return false;
+    if (a.pmax != 0 && t > a.pmax) return false;
+    if (t < a.pmin) return false;
+    if (nc == 1 && same) return false;
+    u64 sumN = a.d;
+    double s = 0;
+    u32 l = 0xFF;
+    for (u32 g = 0; g < a.d; ++g) {
+        u64 f = (u64)x_freq<P>(x, g, v);
+        if (f) {
+            u32 lg = x_pl<P>(x, g, v) >> 4;
+            l = l == 0xFF ? lg : (l == lg ? l : 5u);
+            sumN += f;
+            if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+        }
+    }
+    if (l >= 1 && l <= 4) return false;
+    if (a.emax > 0) {
+        double e = (double)__log2f((float)sumN) - s / (double)sumN;
+        if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) return false;
+    }
+    return true;
+}
+
 struct AdvanceOut {
     u32* slot;        // retained: 4*parent + sym of every new node
     u16* nT;          // per new node
@@ -702,6 +745,11 @@ struct AdvanceOut {
     u32 seg;           // handles per symbol segment of the record buffers
     u32 cap;           // entries of the new level's arrays: a wider level is reported through the total, not written
     u32* h_totals;       // single-tile levels: [0] = nodes of the new level (larger levels: the grand total of the scan)
+    // the output predicates of this level's nodes ride along in the wave sweep (its lanes hold the node's child and reader counts)
+    u32 filter_on;
+    FilterArgs fa;
+    u64* candbits;       // per wave of 64 nodes: which of them are candidates
+    u64* wsum;           // per wave: candidates | pairs << 32
 };
 
 // The few words the host reads after a level travel as ONE 16-byte store to pinned host memory: {sequence number, width of
@@ -865,7 +913,6 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
             if (o.kplane_w) o.kplane_w[(size_t)w * 4 + lane] = DSM_PICK(up, lane);
             if (o.cnt_clear && wi == 0) o.cnt_clear[(size_t)lane * o.nbp + tile] = 0;  // the expand kernels of the next level add into it
         }
-        if (u >= F) continue;
         u32 pres = 0, lastT = 0, vj[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -873,7 +920,17 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
             if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
         }
         const u32 nc = __popc(pres);
-        if (!o.single) o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;
+        const u32 myT = o.single ? 1u : (u < F ? (u32)o.parent_nT[u] : 0u);
+        const u32 same = o.single ? 1u : ((nc == 1 && lastT == myT) ? 1u : 0u);
+        if (o.filter_on) {
+            const bool cand = u < F && filter_node<P>(o.fa, x, u, myT, nc, same);
+            const u64 bits = __ballot(cand);
+            u64 pairs = (u64)__popcll(bits);
+            if (!o.single) pairs = wave_sum_u64(cand ? (u64)myT : 0ull);
+            if (lane == 0) { o.candbits[w] = bits; o.wsum[w] = (u64)__popcll(bits) | (pairs << 32); }
+        }
+        if (u >= F) continue;
+        if (!o.single) o.samechild[u] = (u8)same;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (((pres >> c) & 1u) && vj[c] < o.cap) {
@@ -993,20 +1050,6 @@ __global__ void order_big_kernel(u32 F, Xchg x, const u16* __restrict__ nT, cons
     }
 }
 
-struct FilterArgs {
-    u32 F;
-    u32 depth;
-    u32 d;
-    u32 pmin, pmax, mindepth;
-    double emin, emax;
-    u32 exact_order;  // 0: d == 1; 1: nibble-packed order[] (d <= 13); 2: u16 order arrays (d > 13)
-};
-
-// output predicates of metaserver.cpp:406-419; the entropy test is decided here only when it is not
-// within ENT_MARGIN of a threshold -- everything kept is re-tested on the host with glibc's log (bit-exact).
-// The device value uses the hardware log2 (v_log_f32, 1 ulp: at most 2^-18 absolute for arguments below 2^64), so it
-// is off by less than 1e-5; the margin leaves a factor of ten.
-constexpr double ENT_MARGIN = 1e-4;
 // Per wave of 64 nodes: candbits[w] = which of them are candidates, wsum[w] = their number (low word) and their number of
 // (id, freq) pairs (high word); a scan over the waves gives every wave the place of its first candidate.
 template <typename P>
@@ -2257,11 +2300,14 @@ class Engine {
                 exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
                 if (!merged) ao.cnt_clear = cntraw;
             }
+            // ---- the output predicates for the nodes of THIS level (their children are known now) ride in the wave sweep; the scan of
+            // the candidate counts is queued ahead of the wait ----
+            const bool fused_filter = filtered && nbp > 1;
+            if (fused_filter) { ao.filter_on = 1; ao.fa = filter_args(F, depth, order_mode); ao.candbits = me.cand_bits; ao.wsum = cand_wsum; }
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
             else hipLaunchKernelGGL((advance_wave_kernel<P>), grid_for(F), dim3(256), 0, st, x, ao);
-            // ---- output predicates for the nodes of THIS level (their children are known now): queued ahead of the wait ----
             if (filtered) {
-                if (int erc = emit_filter(me, F, depth, x, cur, order_mode)) return erc;
+                if (int erc = emit_filter(me, F, depth, x, cur, order_mode, !fused_filter)) return erc;
             }
             {
                 PublishArgs pa;
@@ -2418,9 +2464,10 @@ class Engine {
         EARENA_GET(me.cand_bits, u64, ((size_t)F + 63) / 64);
         return 0;
     }
-    int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {
+    int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode, bool run_kernel) {
         const FilterArgs fa = filter_args(F, depth, order_mode);
-        hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild, me.cand_bits, cand_wsum);
+        if (run_kernel)  // (single-tile levels; larger ones evaluate the predicates inside the advance sweep)
+            hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild, me.cand_bits, cand_wsum);
         exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
         return 0;
     }
