@@ -341,12 +341,8 @@ def main():
                 gate.begin(lanes.index(lane))
             with torch.cuda.stream(lane["stream"]):
                 if args.stream_mode:
-                    st = pydsm.Stats()
-                    for pfx in lane["prefixes"]:
-                        nb, s1 = lane["miner"].enumerate(pfx, discard=True)
-                        tot["wire_bytes"] = tot.get("wire_bytes", 0) + (nb if record else 0)
-                        for k, _ in pydsm.Stats._fields_:
-                            setattr(st, k, getattr(st, k) + getattr(s1, k))
+                    nbs, st = lane["miner"].enumerate_many(lane["prefixes"], discard=True)
+                    tot["wire_bytes"] = tot.get("wire_bytes", 0) + (sum(nbs) if record else 0)
                 else:
                     st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
             if record:

@@ -1559,6 +1559,9 @@ __global__ void stream_own_kernel(u32 F, u32 depth, u64 rbase, const P* __restri
     own[v] = b;
 }
 
+// The two tokens of a node: '(' sym at its offset, and varint(freq) ['R' varint(count)] left ')' after its subtree.  Below depth 6
+// the closing token is at most eight bytes for frequencies under 2^32: it is put together in a register and stored as 4 + 2 + 1
+// byte pieces (the addresses have no alignment: the target allows that for global memory) instead of byte by byte.
 template <typename P>
 __global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u32* __restrict__ slot, const P* __restrict__ freq, const u8* __restrict__ left,
                                     const u64* __restrict__ pre, const u64* __restrict__ sz, const u64* __restrict__ off, const u64* __restrict__ bytes,
@@ -1566,12 +1569,27 @@ __global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u32* __re
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
     u8* p = out + off[v];
-    p[0] = '(';
-    p[1] = (u8)"ACGT"[slot[v] & 3];
-    u8* q = out + off[v] + bytes[v] - (own[v] - 2);
-    q += put_varint(q, (u64)freq[v]);
+    const unsigned short head = (unsigned short)('(' | ((0x54474341u >> (8 * (slot[v] & 3))) & 0xFFu) << 8);
+    __builtin_memcpy(p, &head, 2);
+    const u64 f = (u64)freq[v];
+    const u32 lc = (0x4E54474341300000ull >> (8 * (left[v] + 2))) & 0xFFu;  // "0ACGTN"[left]
+    if (depth > 6 && f < (1ull << 32)) {
+        u64 tok;
+        u32 n;
+        if (f < 128) { tok = f | 0x80; n = 1; }
+        else { const u32 l = (u32)((64 - __clzll((long long)f) + 7) >> 3); tok = (u64)l | (f << 8); n = 1 + l; }
+        tok |= ((u64)lc | ((u64)')' << 8)) << (8 * n);
+        n += 2;
+        u8* q = p + bytes[v] - n;
+        if (n & 4) { const u32 w = (u32)tok; __builtin_memcpy(q, &w, 4); q += 4; tok >>= 32; }
+        if (n & 2) { const unsigned short w = (unsigned short)tok; __builtin_memcpy(q, &w, 2); q += 2; tok >>= 16; }
+        if (n & 1) *q = (u8)tok;
+        return;
+    }
+    u8* q = p + bytes[v] - (own[v] - 2);
+    q += put_varint(q, f);
     if (depth <= 6) { *q++ = 'R'; q += put_varint(q, rbase + pre[v] + sz[v]); }
-    *q++ = (u8)"0ACGTN"[left[v]];
+    *q++ = (u8)lc;
     *q = ')';
 }
 
@@ -1862,6 +1880,122 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
     }
     return 0;
 }
+
+// Host worker of the wire-stream path: the bytes of prefix k cross PCIe and reach the sink while the GPU already works on prefix
+// k+1.  Two device buffers alternate between the prefixes; pieces go through two pinned staging buffers.
+struct StreamOut {
+    struct Job { int k; u64 total; int tag; };
+    u8* buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    bool busy[2] = {false, false};
+    hipEvent_t ready[2] = {nullptr, nullptr};  // the write kernels of the buffer's prefix have finished
+    PinBuf pin[2];
+    hipStream_t copy_stream = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    bool stop = false, started = false;
+    int err = 0;  // 1: sink failed, 2: HIP error
+    int device = 0, next = 0;
+    dsm_byte_sink sink = nullptr;
+    dsm_prefix_byte_sink psink = nullptr;
+    void* ctx = nullptr;
+    u64 delivered = 0;
+    static constexpr size_t PIECE = 64u << 20;
+
+    int deliver(const Job& j) {
+        (void)hipSetDevice(device);
+        if (j.total) {
+            if (hipStreamWaitEvent(copy_stream, ready[j.k], 0) != hipSuccess) return 2;
+            const u64 np = (j.total + PIECE - 1) / PIECE;
+            auto bytes = [&](u64 i) { return (size_t)((j.total - i * PIECE) < PIECE ? (j.total - i * PIECE) : PIECE); };
+            if (hipMemcpyAsync(pin[0].p, buf[j.k], bytes(0), hipMemcpyDeviceToHost, copy_stream) != hipSuccess) return 2;
+            for (u64 i = 0; i < np; ++i) {
+                if (hipStreamSynchronize(copy_stream) != hipSuccess) return 2;  // piece i has landed
+                if (i + 1 < np && hipMemcpyAsync(pin[(i + 1) & 1].p, buf[j.k] + (i + 1) * PIECE, bytes(i + 1), hipMemcpyDeviceToHost, copy_stream) != hipSuccess)
+                    return 2;
+                const u8* d = (const u8*)pin[i & 1].p;
+                const int rc = psink ? psink(ctx, j.tag, d, bytes(i)) : (sink ? sink(ctx, d, bytes(i)) : 0);
+                if (rc) { (void)hipStreamSynchronize(copy_stream); return 1; }
+            }
+        }
+        if (psink && psink(ctx, j.tag, nullptr, 0)) return 1;  // end of this prefix
+        return 0;
+    }
+    void loop() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+            }
+            int rc = err ? 0 : deliver(j);  // after a failure the remaining prefixes are dropped
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && !err) err = rc;
+                if (!rc) delivered += j.total;
+                if (j.total) busy[j.k] = false;
+            }
+            cv.notify_all();
+        }
+    }
+    // a free device buffer of at least `total` bytes (blocks while both are still crossing the bus)
+    int acquire(u64 total, int dev, int* k_out) {
+        device = dev;
+        if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(DSM_E_HIP, "hipStreamCreate failed");
+        if (int rc = pin[0].ensure(PIECE)) return rc;
+        if (int rc = pin[1].ensure(PIECE)) return rc;
+        std::unique_lock<std::mutex> lk(mu);
+        const int k = next;
+        cv.wait(lk, [&] { return !busy[k]; });
+        lk.unlock();
+        if (!ready[k] && hipEventCreateWithFlags(&ready[k], hipEventDisableTiming) != hipSuccess) return fail(DSM_E_HIP, "hipEventCreate failed");
+        if (cap[k] < total) {
+            if (buf[k]) (void)hipFree(buf[k]);
+            buf[k] = nullptr;
+            cap[k] = 0;
+            const size_t want = (size_t)total + (size_t)(total / 8) + 4096;
+            hipError_t e = hipMalloc((void**)&buf[k], want);
+            if (e != hipSuccess) return fail(DSM_E_NOMEM, std::string("hipMalloc (wire stream): ") + hipGetErrorString(e));
+            cap[k] = want;
+        }
+        *k_out = k;
+        return 0;
+    }
+    void submit(int k, u64 total, int tag) {  // total == 0: nothing below the root, only the end-of-prefix call
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!started) { started = true; th = std::thread([this] { loop(); }); }
+            if (total) { busy[k] = true; next = k ^ 1; }
+            q.push_back(Job{k, total, tag});
+        }
+        cv.notify_all();
+    }
+    int drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return q.empty() && !busy[0] && !busy[1]; });
+        const int e = err;
+        err = 0;
+        return e;
+    }
+    ~StreamOut() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+        for (int k = 0; k < 2; ++k) {
+            if (buf[k]) (void)hipFree(buf[k]);
+            if (ready[k]) (void)hipEventDestroy(ready[k]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
 
 // Host worker: emits prefix k while the GPU already expands prefix k+1 (two pinned sets).
 struct Emitter {
@@ -2913,7 +3047,10 @@ class Engine {
 
     // ---- stream: byte offsets of every token from subtree sizes ------------------------------------
     int finish_stream(std::vector<LevelHost>& L, u32 nlev, dsm_byte_sink sink, void* ctx) {
-        if (nlev < 2) return 0;  // nothing below the root: the client sends only its handshake
+        if (nlev < 2) {  // nothing below the root: the client sends only its handshake
+            sout.submit(0, 0, stream_tag);
+            return 0;
+        }
         const u64 rbase = 0;     // one connection per call: reported starts at 0 (EnumerateQuery.h:19-21)
         for (u32 l = 0; l < nlev; ++l) {
             ARENA_GET(L[l].sz, u64, L[l].n);
@@ -2946,35 +3083,19 @@ class Engine {
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
-        u8* d_out;
-        ARENA_GET(d_out, u8, total);
+        int k = 0;
+        if (int rc = sout.acquire(total, device, &k)) return rc;  // (waits for the prefix before the previous one to have left the card)
+        u8* d_out = sout.buf[k];
         for (u32 l = 1; l < nlev; ++l)
             hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].slot, (const P*)L[l].freq, L[l].left, L[l].pre,
                                L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
         DSM_HIP(hipGetLastError());
-        // deliver in pieces through two pinned staging buffers: piece k+1 is copied while the sink consumes piece k
-        const size_t PIECE = 64u << 20;
-        if (int rc = stream_pin[0].ensure(PIECE)) return rc;
-        if (int rc = stream_pin[1].ensure(PIECE)) return rc;
-        if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        if (!fill_done) DSM_HIP(hipEventCreateWithFlags(&fill_done, hipEventDisableTiming));
-        DSM_HIP(hipEventRecord(fill_done, st));
-        DSM_HIP(hipStreamWaitEvent(copy_stream, fill_done, 0));
-        int rc = 0;
-        const u64 npieces = (total + PIECE - 1) / PIECE;
-        auto piece_bytes = [&](u64 k) { return (size_t)((total - k * PIECE) < PIECE ? (total - k * PIECE) : PIECE); };
-        if (npieces) DSM_HIP(hipMemcpyAsync(stream_pin[0].p, d_out, piece_bytes(0), hipMemcpyDeviceToHost, copy_stream));
-        for (u64 k = 0; k < npieces && !rc; ++k) {
-            hipError_t e = hipStreamSynchronize(copy_stream);  // piece k has landed
-            if (e != hipSuccess) { rc = fail(DSM_E_HIP, hipGetErrorString(e)); break; }
-            if (k + 1 < npieces)
-                DSM_HIP(hipMemcpyAsync(stream_pin[(k + 1) & 1].p, d_out + (k + 1) * PIECE, piece_bytes(k + 1), hipMemcpyDeviceToHost, copy_stream));
-            if (sink && sink(ctx, (const u8*)stream_pin[k & 1].p, piece_bytes(k))) rc = fail(DSM_E_SINK, "byte sink failed");
-        }
-        if (rc) (void)hipStreamSynchronize(copy_stream);
-        return rc;
+        DSM_HIP(hipEventRecord(sout.ready[k], st));
+        sout.submit(k, total, stream_tag);
+        return 0;
     }
-    PinBuf stream_pin[2];
+    StreamOut sout;
+    int stream_tag = 0;  // index of the prefix being enumerated (dsm_miner_enumerate_many)
 };
 
 static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
@@ -2987,7 +3108,8 @@ static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
 struct MinerBase {
     virtual ~MinerBase() {}
     virtual int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
-    virtual int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
+    virtual int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out,
+                         dsm_prefix_byte_sink ps = nullptr) = 0;
 };
 template <typename P>
 struct MinerT : MinerBase {
@@ -3022,15 +3144,22 @@ struct MinerT : MinerBase {
         return e.run(prefix.c_str(), ts, nullptr, ctx, emit, lo, k, k + 1, seed);
     }
     // prefixes one after the other on the GPU; the host emits prefix k while prefix k+1 is being expanded
-    int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
+    int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out,
+                 dsm_prefix_byte_sink ps = nullptr) override {
         memset(&e.stats, 0, sizeof e.stats);
         int rc = 0;
+        if (e.stream_mode) { e.sout.sink = bs; e.sout.psink = ps; e.sout.ctx = ctx; }
         for (int k = 0; k < n && !rc; ++k) {
             const bool mine = !e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank;
+            e.stream_tag = k;
             if (e.stream_mode) rc = e.run(prefixes[k], ts, bs, ctx, mine);
             else rc = run_auto(prefixes[k] ? prefixes[k] : "", ts, ctx, mine, 1, nullptr);
         }
         int rc2 = e.finish_emits();
+        if (e.stream_mode) {  // the last prefixes may still be on their way to the sink
+            const int se = e.sout.drain();
+            if (se && !rc2) rc2 = fail(se == 1 ? DSM_E_SINK : DSM_E_HIP, se == 1 ? "byte sink failed" : "copying the wire stream to the host failed");
+        }
         e.stats.splits = e.splits;
         e.splits = 0;
         if (out) *out = e.stats;
@@ -3055,7 +3184,13 @@ static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 max
     std::unique_ptr<Engine<P>> e(new Engine<P>());
     dsm_index* one = const_cast<dsm_index*>(idx);
     int rc = e->init(&one, 1, p, true);
-    if (!rc) rc = e->run(prefix, nullptr, sink, ctx);
+    if (!rc) {
+        e->sout.sink = sink;
+        e->sout.ctx = ctx;
+        rc = e->run(prefix, nullptr, sink, ctx);
+        const int se = e->sout.drain();
+        if (se && !rc) rc = fail(se == 1 ? DSM_E_SINK : DSM_E_HIP, se == 1 ? "byte sink failed" : "copying the wire stream to the host failed");
+    }
     if (stats) *stats = e->stats;
     return rc;
 }
@@ -3123,6 +3258,10 @@ int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* 
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
     if (!m) return fail(DSM_E_INVAL, "null miner");
     return reinterpret_cast<MinerBase*>(m)->run(prefix, nullptr, sink, ctx, stats);
+}
+int dsm_miner_enumerate_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_prefix_byte_sink sink, void* ctx, dsm_stats* stats) {
+    if (!m || !prefixes || nprefix < 0) return fail(DSM_E_INVAL, "dsm_miner_enumerate_many: bad arguments");
+    return reinterpret_cast<MinerBase*>(m)->run_many(prefixes, nprefix, nullptr, nullptr, ctx, stats, sink);
 }
 int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
     if (!m || !prefixes || nprefix < 0) return fail(DSM_E_INVAL, "dsm_miner_mine_many: bad arguments");

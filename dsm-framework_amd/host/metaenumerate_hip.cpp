@@ -3,7 +3,8 @@
 //   metaenumerate_hip [-f/--fmin N] [-M/--maxdepth N] [-C/--check] [-v] [--device D] <index.fmi> < hostinfo.txt
 // The reference opens every connection at start-up and walks the prefixes on one OpenMP thread each; here the
 // connections are also opened up front (servers wait for every expected client before they start merging,
-// metaserver.cpp:682-728) and the prefixes are enumerated one after the other on the GPU.
+// metaserver.cpp:682-728) and the prefixes are enumerated one after the other on the GPU, each one's bytes leaving the card and
+// entering its socket while the next is being enumerated.
 #include <getopt.h>
 #include <netdb.h>
 #include <netinet/in.h>
@@ -48,6 +49,13 @@ static int send_all(void* ctx, const uint8_t* p, size_t n) {  // writen(), Clien
         n -= (size_t)w;
     }
     return 0;
+}
+
+// sink of dsm_miner_enumerate_many: pieces of prefix k go to its connection, which is closed when the prefix is complete
+static int send_prefix(void* ctx, int k, const uint8_t* p, size_t n) {
+    std::vector<int*>& fds = *(std::vector<int*>*)ctx;
+    if (!p) { close(*fds[k]); return 0; }
+    return send_all(fds[k], p, n);
 }
 
 int main(int argc, char** argv) {
@@ -112,17 +120,18 @@ int main(int argc, char** argv) {
     dsm_miner* m = nullptr;
     dsm_index* one[1] = {idx};
     if (dsm_miner_create(one, 1, &p, 1, &m)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
-    uint64_t total_occs = 0;
-    for (size_t k = hosts.size(); k-- > 0;) {  // the reference pops hostinfo lines from the back (metaenumerate.cpp:274-275)
-        dsm_stats st;
-        if (dsm_miner_enumerate(m, hosts[k].prefix.c_str(), send_all, &hosts[k].fd, &st)) {
-            std::cerr << "error: " << dsm_last_error() << std::endl;
-            return 1;
-        }
-        close(hosts[k].fd);
-        total_occs += st.reported;
-        if (verbose) std::cerr << "prefix " << hosts[k].prefix << ": " << st.reported << " nodes, expand " << st.expand_ms << " ms" << std::endl;
+    // the reference pops hostinfo lines from the back (metaenumerate.cpp:274-275); all prefixes go down in one call, so the bytes of
+    // one prefix cross PCIe and enter its socket while the GPU enumerates the next
+    std::vector<const char*> order;
+    std::vector<int*> fds;
+    for (size_t k = hosts.size(); k-- > 0;) { order.push_back(hosts[k].prefix.c_str()); fds.push_back(&hosts[k].fd); }
+    dsm_stats st;
+    if (dsm_miner_enumerate_many(m, order.data(), (int)order.size(), send_prefix, &fds, &st)) {
+        std::cerr << "error: " << dsm_last_error() << std::endl;
+        return 1;
     }
+    const uint64_t total_occs = st.reported;
+    if (verbose) std::cerr << order.size() << " prefixes: " << st.reported << " nodes, expand " << st.expand_ms << " ms" << std::endl;
     if (verbose) std::cerr << "Number of reported alignments: " << total_occs << std::endl;
     dsm_miner_destroy(m);
     dsm_index_close(idx);

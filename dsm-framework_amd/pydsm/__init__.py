@@ -49,6 +49,7 @@ class TupleBatch(C.Structure):
 
 
 BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+PREFIX_BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 TUPLE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TupleBatch))
 ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -102,6 +103,7 @@ def lib():
         L.dsm_miner_mine.argtypes = [C.c_void_p, C.c_char_p, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_mine_many.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_enumerate.argtypes = [C.c_void_p, C.c_char_p, BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
+        L.dsm_miner_enumerate_many.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, PREFIX_BYTE_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_miner_destroy.argtypes = [C.c_void_p]
         L.dsm_trie_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_trie_free.argtypes = [C.c_void_p]
@@ -335,6 +337,38 @@ class Miner:
         if with_header:
             body = b"S" + self.indexes[0].name.encode() + b"." + body
         return body, st
+
+    def enumerate_many(self, prefixes, with_header=True, discard=False):
+        """dsm_miner_enumerate_many: the wire streams of several prefixes, the bytes of one crossing PCIe while the GPU works
+        on the next.  -> ([bytes per prefix] or [byte counts] with discard, stats summed over the prefixes)"""
+        chunks = [[] for _ in prefixes]
+        nbytes = [0] * len(prefixes)
+        done = []
+        err = []
+
+        def sink(ctx, k, p, n):
+            try:
+                if not p:
+                    done.append(k)
+                    return 0
+                nbytes[k] += n
+                if not discard:
+                    chunks[k].append(C.string_at(p, n))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through C
+                err.append(e)
+                return 1
+
+        cb = PREFIX_BYTE_SINK(sink)
+        arr = (C.c_char_p * len(prefixes))(*[q.encode() for q in prefixes])
+        st = Stats()
+        _check_sink(lib().dsm_miner_enumerate_many(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
+        if done != list(range(len(prefixes))):
+            raise DsmError("dsm_miner_enumerate_many: prefixes completed as %r" % (done,))
+        if discard:
+            return nbytes, st
+        head = (b"S" + self.indexes[0].name.encode() + b".") if with_header else b""
+        return [head + b"".join(c) for c in chunks], st
 
     def close(self):
         if self.h:

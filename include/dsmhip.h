@@ -210,6 +210,12 @@ int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* 
  * called from a library thread.  stats are summed over the prefixes. */
 int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats);
+/* Several prefixes in one call (the reference client walks its prefixes one after the other, one connection each,
+ * metaenumerate.cpp:268-309): the sink receives (index of the prefix, bytes, n) for consecutive pieces of that prefix's stream
+ * and one call with bytes == NULL, n == 0 when the prefix is complete; prefixes arrive in the given order.  The bytes of
+ * prefix k cross PCIe while the GPU works on prefix k+1.  The sink is called from a library thread. */
+typedef int (*dsm_prefix_byte_sink)(void* ctx, int prefix_index, const uint8_t* bytes, size_t n);
+int dsm_miner_enumerate_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_prefix_byte_sink sink, void* ctx, dsm_stats* stats);
 void dsm_miner_destroy(dsm_miner* m);
 
 /* metaserver's printf formatting of a batch (metaserver.cpp:472-484): "path %f id:freq ...\n".

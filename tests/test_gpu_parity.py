@@ -190,6 +190,17 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
         for p in ["C", "TTG", "C"]:
             got, st = m.enumerate(p)
             assert got == golden.stream("toy3", names[1], p)
+        # several prefixes in one call (their bytes leave the card while the next is enumerated), one with nothing below the root
+        ps = ["A", "C", "G", "T", "AC", "ACGTTTTTTTTTTTTTTTTTTTTTTGGGGGGGGGGGGGGGGGGGGGGG", "GT", "TTG", "ACGTACGTACGT", "C"]
+        got, st = m.enumerate_many(ps)
+        head = b"S" + names[1].encode() + b"."
+        o = orc.Index(golden.fmi("toy3", names[1]))
+        for p, g in zip(ps, got):
+            assert g == (golden.stream("toy3", names[1], p) if len(p) < 20 else o.enumerate(names[1], p, fmin=2)[0]), p
+        o.close()
+        sizes, _ = m.enumerate_many(ps, discard=True)
+        assert sizes == [len(g) - len(head) for g in got]
+        assert m.enumerate_many([])[0] == []
     with pytest.raises(pydsm_mod.DsmError):
         pydsm_mod.Miner(idx, stream_mode=True)
     # an arena too small for the frontier buffers is refused at creation
