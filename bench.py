@@ -362,6 +362,9 @@ def main():
                     tot["record_bytes"] += st.record_bytes
                     tot["slots"] += st.expand_slots
                     tot["colbytes"] += st.expand_column_bytes
+                    tot["splits"] = tot.get("splits", 0) + st.splits
+                    tot["levels"] = tot.get("levels", 0) + st.levels
+                    tot["max_frontier"] = max(tot.get("max_frontier", 0), st.max_frontier)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             if world > 1:  # the other ranks are blocked in a collective: fail the whole job instead of hanging it
@@ -474,6 +477,8 @@ def main():
                          "concurrent_lanes": nlanes},
             "detail": {"rank0_nodes_per_step": tot["reported"] / max(1, args.steps), "rank_ops_per_node": tot["rank_ops"] / max(1, tot["reported"]),
                        "lf_per_node": tot["lf_steps"] / max(1, tot["reported"]), "tuples_per_step": tot["tuples"] / max(1, args.steps),
+                       "prefix_splits_per_step": tot.get("splits", 0) / max(1, args.steps), "levels_per_step": tot.get("levels", 0) / max(1, args.steps),
+                       "max_frontier": tot.get("max_frontier", 0),
                        "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
                        "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
                        "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,

@@ -329,9 +329,6 @@ struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
 
 // One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
 // whose handles are in rn (requested one tile ago); rn then receives the handles of the tile after that.
-// QUEUE (several samples: the lanes hold 64 PRESENT nodes taken from a queue, see expand_queue_kernel): t is the id of the round
-// (its children go to the handles c * seg + 64 * t .., its planes to splane[t]), vcol the lane's node in the union level, hnext the
-// handle of the lane's node of the next round, loc receives 64 * t + lane for every node (the advance sweep finds the plane bit there).
 // SELF (several samples, no handle table): rp is the level's slot array (4 * parent + base per node, shared by all samples) and a
 // node's handle follows from the planes the sample wrote at the parent level (pplane): child c of the parent at round T, lane j has
 // the handle c * seg + 64 * T + (set bits of plane[T][c] below j), and no handle when the bit is clear.  The pipeline is one stage
@@ -347,17 +344,16 @@ __device__ __forceinline__ u32 self_handle(u32 slot, u64 plane, u32 seg) {
 }
 __device__ __forceinline__ size_t self_plane_index(u32 slot) { return slot != DEAD ? (size_t)(slot >> 8) * 4 + (slot & 3u) : (size_t)0; }
 
-template <typename P, bool ONESB, bool INC, bool OUTC, bool QUEUE = false, bool SELF = false>
+template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF = false>
 __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, uint4* wl, const u32* __restrict__ rp, const P* __restrict__ rec,
                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                             u8* __restrict__ pl, const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile,
-                                            const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc, const u32 vcol = 0,
-                                            const u32 hnext = DEAD, u32* __restrict__ loc = nullptr, const u64* __restrict__ pplane = nullptr,
-                                            SelfState* ss = nullptr) {
+                                            const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
+                                            const u64* __restrict__ pplane = nullptr, SelfState* ss = nullptr) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
     const size_t cap = a.cap;
-    const u32 i = QUEUE ? vcol : t * 64 + lane;
+    const u32 i = t * 64 + lane;
     NodeIn<P> nd;
     decode_head(hc, nd);
     const bool live = nd.live;
@@ -410,9 +406,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         }
         // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
         // the blocks leaves them in flight) ----
-        if (QUEUE) {
-            load_head<P>(rec, cap, hnext, hn);
-        } else if (SELF) {
+        if (SELF) {
             load_head<P>(rec, cap, self_handle(ss->s1, ss->pn, a.seg), hn);
             ss->pn = pplane[self_plane_index(ss->s2)];
             ss->s1 = ss->s2;
@@ -556,12 +550,11 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         }
     }
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
-    if (QUEUE ? live : i < a.F) {
+    if (i < a.F) {
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
         else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
         pl[i] = (u8)(present | (mycode << 4));
-        if (QUEUE) loc[i] = t * 64 + (u32)lane;
     }
     acc.kne += k; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
     // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
@@ -606,9 +599,9 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         load_head<P>(rec, a.cap, r0, hA);
         // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
         for (u32 t = gw; t < ntile; t += 2 * nwaves) {
-            expand_tile<P, ONESB, INC, OUTC, false, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, 0, DEAD, nullptr, pplane, &ss);
+            expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, pplane, &ss);
             if (t + nwaves < ntile)
-                expand_tile<P, ONESB, INC, OUTC, false, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, 0, DEAD, nullptr, pplane, &ss);
+                expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss);
         }
     }
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
@@ -637,109 +630,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) =
     expand_sweep<P, ONESB, INC, OUTC>(ix, sbl, parked, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
 }
 
-// The LF-step kernel for runs with several samples.  A sample holds only part of the union level's nodes (about half of them with
-// eight samples of one community), so one thread per union node leaves half of every wave idle.  Here a wave walks a contiguous
-// range of union tiles, drops the absent nodes (their column entries are zeroed on the way) and queues the present ones --
-// (union index, record handle) pairs in an LDS ring -- and every round of expand_tile works on 64 queued nodes: full waves
-// whatever the density.  A round's id t is the union tile of its first node (unique: a tile holds at most 64 nodes), its
-// children and planes go to the areas of t, and loc[node] = 64 t + lane tells the advance sweep where a node's plane bit is.
-constexpr u32 QCAP = 512;  // ring entries per wave (power of two; at most 63 + 64 + 256 are ever queued)
-template <typename P, bool ONESB, bool INC, bool OUTC>
-__device__ __forceinline__ void expand_queue_sweep(const DevIndex& ix, u64* sbl, uint4* parked, uint2* rings, const u32* __restrict__ rp,
-                                                   const P* __restrict__ rec, P* __restrict__ out, u64* __restrict__ splane,
-                                                   u32* __restrict__ loc, P* __restrict__ valf, u8* __restrict__ pl, const ExpandArgs& a,
-                                                   u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
-    uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
-    uint2* ring = rings + (threadIdx.x >> 6) * QCAP;
-    if (!ONESB) {
-        const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
-        for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63;
-    const u64 lt = (1ull << lane) - 1;
-    const u32 nwaves = gridDim.x * 4;
-    const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const u32 ntile = (a.F + 63) >> 6;
-    const u32 per = (ntile + nwaves - 1) / nwaves;
-    u32 nt = gw * per;                                   // next union tile to read
-    const u32 te = nt + per < ntile ? nt + per : ntile;  // end of this wave's range
-    ExpandAcc acc;
-    u32 head = 0, count = 0;  // ring state (wave-uniform)
-    u32 dummy_rn = DEAD;
-    // handles of the next four union tiles, requested one fill ahead
-    u32 pf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const u32 i = (nt + q) * 64 + lane; pf[q] = (nt + q < te && i < a.F) ? rp[i] : DEAD; }
-    auto fill4 = [&]() {  // queue the present nodes of four union tiles, zero the column entries of the absent ones, request the next four
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 i = (nt + q) * 64 + lane;
-            const bool in = nt + q < te && i < a.F;
-            const bool lv = in && pf[q] != DEAD;
-            if (in && !lv) {
-                if (a.w16) reinterpret_cast<u16*>(valf)[i] = 0; else valf[i] = 0;
-                pl[i] = 0;
-            }
-            const u64 m = __ballot(lv);
-            if (lv) ring[(head + count + (u32)__popcll(m & lt)) & (QCAP - 1)] = make_uint2(i, pf[q]);
-            count += (u32)__popcll(m);
-        }
-        nt += 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const u32 i = (nt + q) * 64 + lane; pf[q] = (nt + q < te && i < a.F) ? rp[i] : DEAD; }
-    };
-    while (count < 128 && nt < te) fill4();
-    RecHead<P, INC> hA, hB;
-    {
-        const u32 h0 = (u32)lane < count ? ring[(head + lane) & (QCAP - 1)].y : DEAD;
-        load_head<P>(rec, a.cap, h0, hA);
-    }
-    // two rounds per trip, the two head sets swapping roles (see expand_kernel)
-#define DSM_QUEUE_ROUND(HC, HN)                                                                                                      \
-    {                                                                                                                                \
-        const u32 nr = count < 64 ? count : 64;                                                                                      \
-        while (count - nr < 64 && nt < te) fill4();                                                                                  \
-        const u32 vcol = (u32)lane < nr ? ring[(head + lane) & (QCAP - 1)].x : 0u;                                                   \
-        const u32 hnext = (u32)lane < count - nr ? ring[(head + nr + lane) & (QCAP - 1)].y : DEAD;                                   \
-        const u32 tid = (u32)__builtin_amdgcn_readfirstlane((int)(ring[head & (QCAP - 1)].x >> 6));                                   \
-        expand_tile<P, ONESB, INC, OUTC, true>(ix, sbl, wl, rp, rec, out, splane, nullptr, valf, pl, a, tid, nwaves, ntile, HC, HN,   \
-                                               dummy_rn, acc, vcol, hnext, loc);                                                     \
-        head += nr;                                                                                                                  \
-        count -= nr;                                                                                                                 \
-    }
-    while (count) {
-        DSM_QUEUE_ROUND(hA, hB)
-        if (!count) break;
-        DSM_QUEUE_ROUND(hB, hA)
-    }
-#undef DSM_QUEUE_ROUND
-    // ---- counters: one reduction per wave and launch ----
-    if (__any(acc.wide) && lane == 0) atomicMax(childmax, 65535ull);
-    {
-        u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
-#pragma unroll
-        for (int q = 0; q < NCOUNTERS; ++q) v[q] = wave_sum_u64(v[q]);
-        if (lane < NCOUNTERS) {
-            u64 mine = v[0];
-#pragma unroll
-            for (int q = 1; q < NCOUNTERS; ++q) mine = lane == q ? v[q] : mine;
-            if (mine) atomicAdd((unsigned long long*)&counters[(size_t)(gw & (COUNTER_SHARDS - 1)) * 8 + lane], (unsigned long long)mine);
-        }
-    }
-}
-
-template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(256) void expand_queue_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                                           u64* __restrict__ splane, u32* __restrict__ loc, P* __restrict__ valf,
-                                                           u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
-                                                           unsigned long long* __restrict__ childmax) {
-    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
-    __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
-    __shared__ uint2 rings[4 * QCAP];
-    expand_queue_sweep<P, ONESB, INC, OUTC>(ix, sbl, parked, rings, rp, rec, out, splane, loc, valf, pl, a, counters, childmax);
-}
-
 // Several samples of one process in one launch: blockIdx.y picks the sample (its index, record buffers, columns and code costs come
 // from the batch block), so a level's launches are not eight short ones with eight tails but one wide one.
 struct ExpandSample {
@@ -748,7 +638,6 @@ struct ExpandSample {
     const void* rec;
     void* out;
     u64* splane;
-    u32* loc;       // queue sweep only
     const u64* pplane;  // the planes this sample wrote at the parent level (handles are derived from them, see expand_tile)
     void* valf;
     u8* pl;
@@ -761,12 +650,11 @@ constexpr int BATCH_MAX = 8;
 struct ExpandBatch {
     ExpandSample s[BATCH_MAX];
 };
-template <typename P, bool ONESB, bool INC, bool OUTC, bool QUEUE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) == 4 && !QUEUE ? 4 : 3))) void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters,
-                                                                                                                  unsigned long long* __restrict__ childmax) {
+template <typename P, bool ONESB, bool INC, bool OUTC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) == 4 ? 4 : 3))) void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters,
+                                                                                                        unsigned long long* __restrict__ childmax) {
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
-    __shared__ uint2 rings[QUEUE ? 4 * QCAP : 1];
     const ExpandSample& S = b.s[blockIdx.y];
     a.sb = S.sb;
 #pragma unroll
@@ -774,10 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) =
     a.access_pack = S.access_pack;
     a.costsum_lo = S.costsum_lo;
     a.costsum_hi = S.costsum_hi;
-    if (QUEUE)
-        expand_queue_sweep<P, ONESB, INC, OUTC>(S.ix, sbl, parked, rings, S.rp, (const P*)S.rec, (P*)S.out, S.splane, S.loc, (P*)S.valf, S.pl, a, counters, childmax);
-    else
-        expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
+    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
 }
 
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
@@ -933,7 +818,6 @@ struct AdvanceOut {
     u32* const* rp;             // device table of nlocal pointers: handles of the new level
     u32* rp0;                   // the same for the single sample of a one-sample run (no table to read first)
     const u64* const* splane;   // per local sample: the planes its expand kernel wrote (index mode)
-    const u32* const* loc;      // several samples (index mode): per union node, 64 * round + lane of where the sample's kernel worked on it
     u32 rp_index;               // index mode, several samples: 1 = write the samples' handle tables (0: the expand kernels derive them)
     const u32* const* tpos;     // trie mode: handle of the first allowed child in the parsed stream
     u32 nlocal, rank;
@@ -1062,15 +946,12 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
                         rp[vj[c]] = ((up[c] >> lane) & 1) ? (u32)c * o.seg + (u32)wv * 64u + (u32)__popcll(up[c] & lt) : DEAD;
                     }
                 } else {
-                    const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;  // the children this sample keeps
-                    // round and lane of the node in the sample's kernel: the node's place in the level, or where the queue sweep took it
-                    const u32 lc = o.loc ? (m ? o.loc[sl][u] : 0u) : u;
-                    const u64* sp = o.splane[sl] + (size_t)(lc >> 6) * 4;
-                    const u64 below = (1ull << (lc & 63u)) - 1;
+                    const u64* sp = o.splane[sl] + (size_t)wv * 4;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
-                        rp[vj[c]] = ((m >> c) & 1u) ? (u32)c * o.seg + (lc >> 6) * 64u + (u32)__popcll(sp[c] & below) : DEAD;
+                        const u64 mine = sp[c];
+                        rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + (u32)wv * 64u + (u32)__popcll(mine & lt) : DEAD;
                     }
                 }
             }
@@ -1158,16 +1039,6 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
-            } else if (o.loc) {  // queue sweep: the node was worked on in round loc >> 6 as lane loc & 63
-                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;  // the children this sample keeps
-                const u32 lc = m ? o.loc[sl][u] : 0u;
-                const u64* sp = o.splane[sl] + (size_t)(lc >> 6) * 4;
-                const u64 below = (1ull << (lc & 63u)) - 1;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
-                    rp[vj[c]] = ((m >> c) & 1u) ? (u32)c * o.seg + (lc >> 6) * 64u + (u32)__popcll(sp[c] & below) : DEAD;
-                }
             } else {
                 const u64* sp = o.splane[sl] + (size_t)w * 4;
 #pragma unroll
@@ -2139,12 +2010,8 @@ class Engine {
     u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*], tpos[*] and splane[*] for the advance kernel
     u32** d_tpos_tab = nullptr;
     u64** d_splane_tab = nullptr;
-    std::vector<u32*> locs;     // several samples, index mode: where each union node was worked on (see expand_queue_kernel)
-    u32** d_loc_tab = nullptr;
-    u32 queue_blocks = 768;     // resident blocks of the queue variant of the LF-step kernel
-    bool queue_mode = false;    // several samples: the queue sweep instead of one lane per union node (DSM_QUEUE=1)
     bool batch_mode = true;     // several samples: one launch per level for up to BATCH_MAX of this process's, handles derived in the kernel
-    bool self_mode = false;     // = several samples, index mode, batch_mode and not queue_mode: no handle tables (see expand_tile, SELF)
+    bool self_mode = false;     // = several samples, index mode, batch_mode: no handle tables (see expand_tile, SELF)
     std::vector<u64*> splane2;  // self_mode: second plane buffer per sample (a level reads its parent level's planes while writing its own)
     u8* xsend = nullptr;
     u8* xrecv[2] = {nullptr, nullptr};
@@ -2241,9 +2108,8 @@ class Engine {
         DSM_HIP(hipSetDevice(device));
         size_t free_b = 0, total_b = 0;
         DSM_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (const char* e = getenv("DSM_QUEUE")) queue_mode = atoi(e) != 0;
         if (const char* e = getenv("DSM_BATCH")) batch_mode = atoi(e) != 0;
-        self_mode = d > 1 && !trie_mode && batch_mode && !queue_mode;
+        self_mode = d > 1 && !trie_mode && batch_mode;
         // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
         // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
         const u64 fbound = (world > 1 ? (u64)d * nmax : nsum) + 16;
@@ -2306,13 +2172,10 @@ class Engine {
             }
             if (int rc = dalloc(r0, (size_t)Fcap)) return rc;
             if (int rc = dalloc(r1, (size_t)Fcap)) return rc;
-            u32* lc = nullptr;
-            if (!trie_mode && d > 1 && queue_mode) { if (int rc = dalloc(lc, (size_t)Fcap)) return rc; }
             u64* pln2 = nullptr;
             if (self_mode) { if (int rc = dalloc(pln2, nwave * 4)) return rc; }
             splane2.push_back(pln2);
             rec[0].push_back(a); rec[1].push_back(b); rp[0].push_back(r0); rp[1].push_back(r1); tpos.push_back(tp); splane.push_back(pln);
-            locs.push_back(lc);
         }
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(d_rp_tab[k], (size_t)nlocal)) return rc;
@@ -2322,8 +2185,6 @@ class Engine {
         DSM_HIP(hipMemcpy(d_tpos_tab, tpos.data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
         if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
-        if (int rc = dalloc(d_loc_tab, (size_t)nlocal)) return rc;
-        DSM_HIP(hipMemcpy(d_loc_tab, locs.data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
         if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
         if (d == 1 && !trie_mode) {
             if (int rc = dalloc(cntraw, 4 * ntile + 8)) return rc;
@@ -2336,11 +2197,6 @@ class Engine {
             if (const char* e = getenv("DSM_EXPAND_BLOCKS_PER_CU")) per = atoi(e);
             if (per < 1) per = 1;
             expand_blocks = (u32)(cus > 0 ? cus : 256) * (u32)per;
-            int perq = 0;
-            DSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perq, (expand_queue_kernel<P, true, true, true>), 256, 0));
-            if (const char* e = getenv("DSM_QUEUE_BLOCKS_PER_CU")) perq = atoi(e);
-            if (perq < 1) perq = 1;
-            queue_blocks = (u32)(cus > 0 ? cus : 256) * (u32)perq;
         }
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
@@ -2568,7 +2424,6 @@ class Engine {
                     DSM_HIP(hipMemsetAsync(cl, 0, (size_t)F, st));
                 }
             }
-            const bool queued = d > 1 && queue_mode;  // several samples: full waves of present nodes (expand_queue_sweep)
             const u32 need = (F + TILE - 1) / TILE;
             ExpandBatch eb;
             int nb = 0;
@@ -2578,7 +2433,7 @@ class Engine {
                 const IndexMeta& m = idx[s]->meta;
                 ExpandSample& es = eb.s[nb];
                 es.ix = idx[s]->dev;
-                es.rp = rp[cur][s]; es.rec = rec[cur][s]; es.out = rec[nxt][s]; es.splane = splane[s]; es.loc = locs[s];
+                es.rp = rp[cur][s]; es.rec = rec[cur][s]; es.out = rec[nxt][s]; es.splane = splane[s];
                 es.pplane = nullptr;
                 if (self_mode) {  // handles from the level's slots and the planes of the parent level (the two plane buffers alternate)
                     es.rp = lslot;
@@ -2612,18 +2467,14 @@ class Engine {
         if (fmt_in) { if (oc) LAUNCH(SB, true, true); else LAUNCH(SB, true, false); }         \
         else { if (oc) LAUNCH(SB, false, true); else LAUNCH(SB, false, false); }              \
     } while (0)
-                if (self_mode || (nlocal > 1 && batch_mode)) {  // several samples: one launch for up to BATCH_MAX of this process's
+                if (self_mode) {  // several samples: one launch for up to BATCH_MAX of this process's
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;
-                    const u32 resident = queued ? queue_blocks : expand_blocks;
-                    u32 gx = 2 * resident / (u32)nb;
+                    u32 gx = 2 * expand_blocks / (u32)nb;
                     if (gx < 1) gx = 1;
                     const dim3 bg(need < gx ? need : gx, (u32)nb);
-#define DSM_LAUNCH_BATCH_Q(SB, IC, OC) hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC, true>), bg, dim3(256), 0, st, eb, ea, d_counters, d_childmax)
-#define DSM_LAUNCH_BATCH_P(SB, IC, OC) hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC, false>), bg, dim3(256), 0, st, eb, ea, d_counters, d_childmax)
-                    if (queued) { if (all_one_sb) DSM_FORMATS(DSM_LAUNCH_BATCH_Q, true); else DSM_FORMATS(DSM_LAUNCH_BATCH_Q, false); }
-                    else { if (all_one_sb) DSM_FORMATS(DSM_LAUNCH_BATCH_P, true); else DSM_FORMATS(DSM_LAUNCH_BATCH_P, false); }
-#undef DSM_LAUNCH_BATCH_Q
-#undef DSM_LAUNCH_BATCH_P
+#define DSM_LAUNCH_BATCH(SB, IC, OC) hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), bg, dim3(256), 0, st, eb, ea, d_counters, d_childmax)
+                    if (all_one_sb) DSM_FORMATS(DSM_LAUNCH_BATCH, true); else DSM_FORMATS(DSM_LAUNCH_BATCH, false);
+#undef DSM_LAUNCH_BATCH
                     nb = 0;
                     ++stats.expand_launches;
                     continue;
@@ -2636,18 +2487,12 @@ class Engine {
                 P* cf = reinterpret_cast<P*>(es.valf);
                 u8* cl = es.pl;
                 const dim3 eg(need < expand_blocks ? need : expand_blocks);
-                const dim3 qg(need < queue_blocks ? need : queue_blocks);
                 u32* ecnt = (d == 1 && ea.nbp > 1) ? cntraw : (u32*)nullptr;
 #define DSM_LAUNCH_EXPAND(SB, IC, OC)                                                                                               \
     hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], \
                        ecnt, cf, cl, ea, d_counters, d_childmax)
-#define DSM_LAUNCH_QUEUE(SB, IC, OC)                                                                                                \
-    hipLaunchKernelGGL((expand_queue_kernel<P, SB, IC, OC>), qg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s],  \
-                       splane[s], locs[s], cf, cl, ea, d_counters, d_childmax)
-                if (queued) { if (one_sb) DSM_FORMATS(DSM_LAUNCH_QUEUE, true); else DSM_FORMATS(DSM_LAUNCH_QUEUE, false); }
-                else { if (one_sb) DSM_FORMATS(DSM_LAUNCH_EXPAND, true); else DSM_FORMATS(DSM_LAUNCH_EXPAND, false); }
+                if (one_sb) DSM_FORMATS(DSM_LAUNCH_EXPAND, true); else DSM_FORMATS(DSM_LAUNCH_EXPAND, false);
 #undef DSM_LAUNCH_EXPAND
-#undef DSM_LAUNCH_QUEUE
 #undef DSM_FORMATS
                 ++stats.expand_launches;
             }
@@ -2707,7 +2552,6 @@ class Engine {
             ao.rp0 = rp[nxt][0];
             ao.tpos = trie_mode ? d_tpos_tab : nullptr;
             ao.splane = d_splane_tab;
-            ao.loc = (queue_mode && d > 1) ? d_loc_tab : nullptr;
             ao.rp_index = self_mode ? 0u : 1u;
             ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp;
             const bool merged = d > 1 || trie_mode;  // the union of several columns (a parsed stream is treated alike)
