@@ -154,6 +154,7 @@ __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
 constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=record bytes read + written [5]=records read
 constexpr u32 DEAD = 0xFFFFFFFFu;
+constexpr u32 PACK_FMAX = 512;        // a level whose frequencies are all below this packs frequency and flags of a node into 16 bits
 constexpr u32 TILE = 256;             // parents per block of the expand / advance kernels
 
 // Children directory of a level ("kids"): per 64 nodes (one wave) four bit planes -- bit j of plane c: node 64w + j has a child
@@ -201,7 +202,9 @@ struct ExpandArgs {
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
     u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
-    u32 w16;          // this level's frequency column is 16 bits wide (every node of the level has freq < 65535)
+    u32 w16;          // this level's column: 0 = frequencies as P plus a flag byte; 1 = 16-bit frequencies plus a flag byte (every
+                      // frequency of the level is below 65535); 2 = ONE 16-bit word per node, frequency in bits 0-8 and the flags
+                      // in bits 9-15 (every frequency below 512: all but the top levels of a prefix)
     SbArgs sb;        // superblock bases of this sample's index
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_pack;  // BitRank::rank calls of getL by 3-bit code, four bits each (a table in the argument block would be a load)
@@ -324,7 +327,7 @@ struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
     // (k <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
     u32 kne = 0, ll = 0, lf = 0, rank = 0;
     u32 rbytes = 0;     // bytes of records read and written
-    bool wide = false;  // some surviving child has a frequency of 65535 or more (decides the next level's column width)
+    u32 wide = 0;       // bit 0: some surviving child has a frequency of 512 or more, bit 1: of 65535 or more (the next level's column format)
 };
 
 // One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
@@ -442,7 +445,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                     nonempty |= 1u << c;
                     if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
                         present |= 1u << c;
-                        if ((u64)(nep - nsp) + 1 >= 65535) acc.wide = true;
+                        if ((u64)(nep - nsp) + 1 >= PACK_FMAX) acc.wide |= (u64)(nep - nsp) + 1 >= 65535 ? 3u : 1u;
                     }
                 }
             }
@@ -552,9 +555,13 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
     if (i < a.F) {
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
-        if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
-        else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
-        pl[i] = (u8)(present | (mycode << 4));
+        if (a.w16 == 2) {
+            reinterpret_cast<u16*>(valf)[i] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
+        } else {
+            if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
+            else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
+            pl[i] = (u8)(present | (mycode << 4));
+        }
     }
     acc.kne += k; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
     // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
@@ -605,7 +612,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         }
     }
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
-    if (__any(acc.wide) && lane == 0) atomicMax(childmax, 65535ull);  // only "65535 or more" matters (and it is rare)
+    if (__any(acc.wide != 0) && lane == 0) atomicMax(childmax, __any((acc.wide & 2u) != 0) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
     {
         u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
 #pragma unroll
@@ -684,7 +691,8 @@ struct Xchg {
     u32 nlocal;
     u32 d;        // total samples = world * nlocal
     u64 F;        // nodes of the level
-    u32 fb;       // bytes per frequency entry: 2 when every frequency of the level is below 65535, else sizeof(P)
+    u32 fb;       // bytes per frequency entry: 2 when every frequency of the level is below 65535, else sizeof(P); 1 = packed: one
+                  // 16-bit word per node and nothing else (frequency below 512 in bits 0-8, the flag byte in bits 9-15)
 };
 __device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
     if (x.nlocal == 1) { r = g; l = 0; }          // one sample per rank (multi-GPU runs)
@@ -696,6 +704,7 @@ __device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
     const u8* rb = x.base + (u64)r * x.bpr + XHDR;
+    if (x.fb == 1) return (P)(reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v] & (PACK_FMAX - 1));
     if (x.fb == 2) return (P)reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v];
     return reinterpret_cast<const P*>(rb)[(u64)l * x.F + v];
 }
@@ -703,6 +712,7 @@ template <typename P>
 __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
+    if (x.fb == 1) return (u32)reinterpret_cast<const u16*>(x.base + (u64)r * x.bpr + XHDR)[(u64)l * x.F + v] >> 9;
     const u8* rb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
     return rb[(u64)l * x.F + v];
 }
@@ -722,6 +732,15 @@ __device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) nT4[c] = 0;
     for (u32 r = 0; r < world; ++r) {
+        if (x.fb == 1) {  // packed columns: the children nibble sits in bits 9-12 of the node's word
+            const u16* pw = reinterpret_cast<const u16*>(x.base + (u64)r * x.bpr + XHDR);
+            for (u32 l = 0; l < x.nlocal; ++l) {
+                const u32 m = (u32)pw[(u64)l * x.F + u] >> 9;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nT4[c] += (m >> c) & 1u;
+            }
+            continue;
+        }
         const u8* pb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
         for (u32 l = 0; l < x.nlocal; ++l) {
             const u32 m = pb[(u64)l * x.F + u];
@@ -846,17 +865,19 @@ struct PublishArgs {
     u32 seq;
 };
 __global__ void publish_kernel(PublishArgs a) {
-    __shared__ u32 wide;
+    __shared__ u32 wide;  // bit 0: some child frequency of the level is 65535 or more, bit 1: 512 or more
     if (threadIdx.x == 0) wide = 0;
     __syncthreads();
-    for (u32 r = threadIdx.x; r < a.cmax_world; r += blockDim.x)
-        if (*reinterpret_cast<const u64*>(a.cmax_base + (u64)r * a.cmax_bpr) >= 65535) wide = 1;
+    for (u32 r = threadIdx.x; r < a.cmax_world; r += blockDim.x) {
+        const u64 m = *reinterpret_cast<const u64*>(a.cmax_base + (u64)r * a.cmax_bpr);
+        if (m >= PACK_FMAX) atomicOr(&wide, m >= 65535 ? 3u : 2u);
+    }
     const u32 tot = threadIdx.x == 0 ? *a.total : 0u;
     const u64 cand = threadIdx.x == 0 && a.cand ? *a.cand : 0ull;
     __syncthreads();
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-        *a.packet = make_uint4(a.seq, tot | (wide << 31), (u32)cand, (u32)(cand >> 32));  // one global_store_dwordx4
+        *a.packet = make_uint4(a.seq, tot | ((wide & 1u) << 31) | ((wide >> 1) << 30), (u32)cand, (u32)(cand >> 32));  // one global_store_dwordx4
     }
 }
 
@@ -2010,6 +2031,7 @@ class Engine {
     u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*], tpos[*] and splane[*] for the advance kernel
     u32** d_tpos_tab = nullptr;
     u64** d_splane_tab = nullptr;
+    bool pack_columns = true;   // levels whose frequencies are all below 512: one 16-bit column word per node (DSM_PACK=0 turns it off)
     bool batch_mode = true;     // several samples: one launch per level for up to BATCH_MAX of this process's, handles derived in the kernel
     bool self_mode = false;     // = several samples, index mode, batch_mode: no handle tables (see expand_tile, SELF)
     std::vector<u64*> splane2;  // self_mode: second plane buffer per sample (a level reads its parent level's planes while writing its own)
@@ -2109,6 +2131,7 @@ class Engine {
         size_t free_b = 0, total_b = 0;
         DSM_HIP(hipMemGetInfo(&free_b, &total_b));
         if (const char* e = getenv("DSM_BATCH")) batch_mode = atoi(e) != 0;
+        if (const char* e = getenv("DSM_PACK")) pack_columns = atoi(e) != 0;
         self_mode = d > 1 && !trie_mode && batch_mode;
         // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
         // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
@@ -2377,6 +2400,7 @@ class Engine {
         // Width of the frequency column of the level about to be exchanged.  Every rank derives it from the same number: the
         // largest frequency any sample has at that level, carried in the previous level's exchange (the root level is wide).
         bool w16 = false;
+        bool w9 = false;   // ... and below 512: one 16-bit word per node holds frequency and flags
         int cur = 0;      // ping-pong index of the current level (rec, rp, nT, order)
         int xcur = 0;     // exchange buffer that will receive the current level's children
         u32 F = 1;
@@ -2386,17 +2410,19 @@ class Engine {
         // the host to get through them.
         const bool trace_levels = getenv("DSM_TRACE_LEVELS") != nullptr;  // debugging aid: widths of the levels on stderr
         bool fmt_in = false;  // format of the records of the level about to be expanded (the root's record is wide)
-        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, const u32* lslot) -> int {
+        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, bool w9, const u32* lslot) -> int {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
-            const u32 fb = w16 ? 2u : (u32)sizeof(P);
+            const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
+            const u32 colb = w9 ? 2u : fb + 1;  // column bytes per node
             // per rank: 16-byte header (largest child frequency of this level), [nlocal][F] frequencies, [nlocal][F] bytes, padding
-            const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
+            // (packed levels: [nlocal][F] 16-bit words)
+            const u64 bpr = (((u64)nlocal * F * colb + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
             u8* send = multi ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
-            ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w16 ? 1u : 0u;
+            ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w9 ? 2u : (w16 ? 1u : 0u);
             unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send);  // header, cleared by the previous level's publish kernel
             if (depth < prefix.size()) {
                 const char* q = strchr(bases, prefix[depth]);
@@ -2440,8 +2466,8 @@ class Engine {
                     es.splane = (depth & 1) ? splane2[s] : splane[s];
                     es.pplane = (depth & 1) ? splane[s] : splane2[s];
                 }
-                es.valf = send + XHDR + (size_t)s * F * fb;                      // this sample's frequency column
-                es.pl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;   // children nibble | left char << 4
+                es.valf = send + XHDR + (size_t)s * F * (w9 ? 2u : fb);         // this sample's frequency column (packed: its words)
+                es.pl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;   // children nibble | left char << 4 (not used when packed)
                 for (int c = 0; c < 4; ++c) es.cost[c] = m.lfcost[c];
                 for (int c = 0; c < 4; ++c) es.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
                 es.costsum_lo = es.costsum_hi = 0;
@@ -2459,7 +2485,7 @@ class Engine {
                 }
                 ++nb;
                 stats.expand_slots += F;
-                stats.expand_column_bytes += (u64)F * (fb + 1);
+                stats.expand_column_bytes += (u64)F * colb;
                 const bool oc = w16;
                 // record formats: this level's records are compact iff its parent level was narrow (fmt_in), the children's iff this one is
 #define DSM_FORMATS(LAUNCH, SB)                                                               \
@@ -2504,11 +2530,11 @@ class Engine {
             return 0;
         };
         DSM_HIP(hipMemsetAsync(multi ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
-        if (int rc = launch_expand(F, depth, cur, xcur, w16, L[0].slot)) return rc;
+        if (int rc = launch_expand(F, depth, cur, xcur, w16, w9, L[0].slot)) return rc;
         while (true) {
             const u64 slots = (u64)F * 4;
-            const u32 fb = w16 ? 2u : (u32)sizeof(P);
-            const u64 bpr = (((u64)nlocal * F * (fb + 1) + 15) & ~15ull) + 16;
+            const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
+            const u64 bpr = (((u64)nlocal * F * (w9 ? 2u : fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
             // ---- exchange: one all-gather per level ----------------------------------------------
             if (multi) {
@@ -2602,8 +2628,9 @@ class Engine {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 for (int q = 0; q < 4; ++q) pk[q] = fl[q];
             }
-            const u32 Fn = pk[1] & 0x7FFFFFFFu;
+            const u32 Fn = pk[1] & 0x3FFFFFFFu;
             w16 = !(pk[1] >> 31) && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
+            w9 = w16 && !((pk[1] >> 30) & 1u) && pack_columns;  // ... and nine: frequency and flags share a 16-bit word
             h_totals[300] = pk[2]; h_totals[301] = pk[3];  // candidate totals of this level (read by emit_store)
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             // commit the provisional window at its real size
@@ -2612,7 +2639,7 @@ class Engine {
             if (Fn) {
                 child.slot = arena.get<u32>(Fn);  // same address as new_slot2
                 if (int rc = alloc_kids(child)) return rc;
-                if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16, child.slot)) return rc;  // w16 already describes the next level
+                if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16, w9, child.slot)) return rc;  // w16, w9 already describe the next level
                 // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
                 if (!(emit || capture)) {}
                 else if (order_mode == 1)
