@@ -5,10 +5,16 @@
 // HuffWT::access semantics (HuffWT.h:126-140) and transcoded into the interleaved bit-plane blocks
 // of common.h.  The raw tree is dropped afterwards unless DSM_OPEN_KEEP_WT asks to keep it for the
 // node-by-node LF kernel (HuffWT::rank semantics, HuffWT.h:66-83).
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "scan.h"
@@ -213,6 +219,84 @@ struct Parser {
     }
 };
 
+struct MappedFile {
+    const u8* p = nullptr;
+    size_t n = 0;
+    int open(const char* path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(DSM_E_NOENT, std::string("file not found: ") + path);
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { ::close(fd); return fail(DSM_E_IO, "fstat failed"); }
+        n = (size_t)sb.st_size;
+        if (n == 0) { ::close(fd); return fail(DSM_E_IO, "truncated or corrupt .fmi"); }
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) { n = 0; return fail(DSM_E_IO, "mmap failed"); }
+        (void)madvise(m, n, MADV_SEQUENTIAL);
+        p = (const u8*)m;
+        return 0;
+    }
+    void close() {
+        if (p) munmap((void*)p, n);
+        p = nullptr;
+        n = 0;
+    }
+    ~MappedFile() { close(); }
+};
+
+// Host ranges -> device, chunk by chunk through pinned staging buffers, on a few threads: a thread copies a chunk out of the
+// mapping (which is what faults the pages in) while its previous chunk is on the bus.  The buffers are kept for the next index.
+struct UploadPiece { u8* dst; const u8* src; size_t n; };
+struct StagePool {
+    static constexpr int THREADS = 4;
+    static constexpr size_t CHUNK = 8u << 20;
+    std::mutex mu;  // one upload at a time uses the pool
+    void* buf[THREADS][2] = {{nullptr}};
+    int ensure() {
+        for (int t = 0; t < THREADS; ++t)
+            for (int k = 0; k < 2; ++k)
+                if (!buf[t][k] && hipHostMalloc(&buf[t][k], CHUNK) != hipSuccess) return fail(DSM_E_NOMEM, "hipHostMalloc (index staging) failed");
+        return 0;
+    }
+};
+static StagePool g_stage;
+static int staged_upload(const std::vector<UploadPiece>& pieces, int device) {
+    struct Chunk { u8* dst; const u8* src; size_t n; };
+    std::vector<Chunk> chunks;
+    for (const UploadPiece& q : pieces)
+        for (size_t o = 0; o < q.n; o += StagePool::CHUNK) chunks.push_back(Chunk{q.dst + o, q.src + o, q.n - o < StagePool::CHUNK ? q.n - o : StagePool::CHUNK});
+    std::lock_guard<std::mutex> lk(g_stage.mu);
+    if (int rc = g_stage.ensure()) return rc;
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) { bad = 1; return; }
+        hipStream_t st;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { bad = 1; return; }
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool used[2] = {false, false};
+        if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) bad = 1;
+        for (int k = 0; !bad; k ^= 1) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size()) break;
+            if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { bad = 1; break; }  // the buffer's previous chunk has left
+            memcpy(g_stage.buf[t][k], chunks[i].src, chunks[i].n);
+            if (hipMemcpyAsync(chunks[i].dst, g_stage.buf[t][k], chunks[i].n, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { bad = 1; break; }
+            used[k] = true;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) bad = 1;
+        for (int k = 0; k < 2; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+        (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th;
+    const int nth = chunks.size() < (size_t)StagePool::THREADS ? (int)chunks.size() : StagePool::THREADS;
+    for (int t = 1; t < nth; ++t) th.emplace_back(work, t);
+    if (nth > 0) work(0);
+    for (auto& x : th) x.join();
+    if (bad) return fail(DSM_E_HIP, "uploading the index failed");
+    return 0;
+}
+
 static int parse_node(Parser& r, std::vector<HostNode>& nodes, int depth) {
     int id = (int)nodes.size();
     nodes.emplace_back();
@@ -265,17 +349,13 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
     if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_index_open: bad device ordinal");
     DSM_HIP(hipSetDevice(device));
 
-    FILE* f = fopen(path, "rb");
-    if (!f) return fail(DSM_E_NOENT, std::string("file not found: ") + path);
-    struct stat sb;
-    if (fstat(fileno(f), &sb) != 0) { fclose(f); return fail(DSM_E_IO, "fstat failed"); }
-    size_t fsz = (size_t)sb.st_size;
-    std::vector<u8> file(fsz);
-    size_t got = fread(file.data(), 1, fsz, f);
-    fclose(f);
-    if (got != fsz) return fail(DSM_E_IO, "short read");
+    // The file is mapped, not read: the header is parsed in place and the bit vectors go from the page cache through pinned
+    // staging buffers to the card on several threads (a vector + fread + pageable hipMemcpy moved every byte three times on one).
+    MappedFile file;
+    if (int rc = file.open(path)) return rc;
+    const size_t fsz = file.n;
 
-    Parser r{file.data(), fsz};
+    Parser r{file.p, fsz};
     u8 ver = r.rd<u8>();
     if (!r.ok || (ver != 17 && ver != 16 && ver != 15 && ver != 14))
         return fail(DSM_E_FORMAT, "FMIndex: invalid save file version (expected 14..17)");
@@ -344,16 +424,19 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
     DevBuf<WtNodeDev> d_nodes;
     DSM_HIP(d_blob.alloc(blob_bytes));
     DSM_HIP(d_nodes.alloc(wn.size()));
-    for (size_t k = 0; k < nodes.size(); ++k) {
-        const HostNode& h = nodes[k];
-        if (h.leaf) continue;
-        DSM_HIP(hipMemcpy(d_blob.p + wn[k].data_off, file.data() + h.data_pos, 8 * h.integers, hipMemcpyHostToDevice));
-        DSM_HIP(hipMemcpy(d_blob.p + wn[k].rs_off, file.data() + h.rs_pos, 8 * (h.nbits / 256 + 1), hipMemcpyHostToDevice));
-        DSM_HIP(hipMemcpy(d_blob.p + wn[k].rb_off, file.data() + h.rb_pos, h.nbits / 64 + 1, hipMemcpyHostToDevice));
+    {
+        std::vector<UploadPiece> pieces;
+        for (size_t k = 0; k < nodes.size(); ++k) {
+            const HostNode& h = nodes[k];
+            if (h.leaf) continue;
+            pieces.push_back(UploadPiece{d_blob.p + wn[k].data_off, file.p + h.data_pos, (size_t)8 * h.integers});
+            pieces.push_back(UploadPiece{d_blob.p + wn[k].rs_off, file.p + h.rs_pos, (size_t)8 * (h.nbits / 256 + 1)});
+            pieces.push_back(UploadPiece{d_blob.p + wn[k].rb_off, file.p + h.rb_pos, (size_t)(h.nbits / 64 + 1)});
+        }
+        if (int rc = staged_upload(pieces, device)) return rc;
     }
     DSM_HIP(hipMemcpy(d_nodes.p, wn.data(), wn.size() * sizeof(WtNodeDev), hipMemcpyHostToDevice));
-    file.clear();
-    file.shrink_to_fit();
+    file.close();
 
     const u64 n = m.n;
     const u64 nblk = (n >> BLK_SHIFT) + 1;
