@@ -1776,7 +1776,7 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
 // Host worker of the wire-stream path: the bytes of prefix k cross PCIe and reach the sink while the GPU already works on prefix
 // k+1.  Two device buffers alternate between the prefixes; pieces go through two pinned staging buffers.
 struct StreamOut {
-    struct Job { int k; u64 total; int tag; };
+    struct Job { int k; u64 total; int tag; u64 off; u64 len; bool last; };  // bytes [off, off + len) of the buffer; last: the prefix ends here
     u8* buf[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     bool busy[2] = {false, false};
@@ -1800,19 +1800,20 @@ struct StreamOut {
         (void)hipSetDevice(device);
         if (j.total) {
             if (hipStreamWaitEvent(copy_stream, ready[j.k], 0) != hipSuccess) return 2;
-            const u64 np = (j.total + PIECE - 1) / PIECE;
-            auto bytes = [&](u64 i) { return (size_t)((j.total - i * PIECE) < PIECE ? (j.total - i * PIECE) : PIECE); };
-            if (hipMemcpyAsync(pin[0].p, buf[j.k], bytes(0), hipMemcpyDeviceToHost, copy_stream) != hipSuccess) return 2;
+            const u8* src = buf[j.k] + j.off;
+            const u64 np = (j.len + PIECE - 1) / PIECE;
+            auto bytes = [&](u64 i) { return (size_t)((j.len - i * PIECE) < PIECE ? (j.len - i * PIECE) : PIECE); };
+            if (np && hipMemcpyAsync(pin[0].p, src, bytes(0), hipMemcpyDeviceToHost, copy_stream) != hipSuccess) return 2;
             for (u64 i = 0; i < np; ++i) {
                 if (hipStreamSynchronize(copy_stream) != hipSuccess) return 2;  // piece i has landed
-                if (i + 1 < np && hipMemcpyAsync(pin[(i + 1) & 1].p, buf[j.k] + (i + 1) * PIECE, bytes(i + 1), hipMemcpyDeviceToHost, copy_stream) != hipSuccess)
+                if (i + 1 < np && hipMemcpyAsync(pin[(i + 1) & 1].p, src + (i + 1) * PIECE, bytes(i + 1), hipMemcpyDeviceToHost, copy_stream) != hipSuccess)
                     return 2;
                 const u8* d = (const u8*)pin[i & 1].p;
                 const int rc = psink ? psink(ctx, j.tag, d, bytes(i)) : (sink ? sink(ctx, d, bytes(i)) : 0);
                 if (rc) { (void)hipStreamSynchronize(copy_stream); return 1; }
             }
         }
-        if (psink && psink(ctx, j.tag, nullptr, 0)) return 1;  // end of this prefix
+        if (j.last && psink && psink(ctx, j.tag, nullptr, 0)) return 1;  // end of this prefix
         return 0;
     }
     void loop() {
@@ -1829,7 +1830,7 @@ struct StreamOut {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc && !err) err = rc;
-                if (!rc) delivered += j.total;
+                if (!rc) delivered += j.len;
                 if (j.total) busy[j.k] = false;
             }
             cv.notify_all();
@@ -1858,12 +1859,12 @@ struct StreamOut {
         *k_out = k;
         return 0;
     }
-    void submit(int k, u64 total, int tag) {  // total == 0: nothing below the root, only the end-of-prefix call
+    void submit(int k, u64 total, int tag, u64 off, u64 len, bool last) {  // total == 0: nothing below the root, only the end-of-prefix call
         {
             std::lock_guard<std::mutex> lk(mu);
             if (!started) { started = true; th = std::thread([this] { loop(); }); }
             if (total) { busy[k] = true; next = k ^ 1; }
-            q.push_back(Job{k, total, tag});
+            q.push_back(Job{k, total, tag, off, len, last});
         }
         cv.notify_all();
     }
@@ -2702,7 +2703,7 @@ class Engine {
 
         bool ready = false;
         if (stream_mode) {
-            if (int rc = finish_stream(L, nlev, bsink, ctx)) return rc;
+            if (emit) { if (int rc = finish_stream(L, nlev, bsink, ctx)) return rc; }
         } else {
             if (emitting) {
                 int rc = finish_mine(L, nlev, tsink, ctx, &ready);
@@ -2919,10 +2920,11 @@ class Engine {
     // ---- stream: byte offsets of every token from subtree sizes ------------------------------------
     int finish_stream(std::vector<LevelHost>& L, u32 nlev, dsm_byte_sink sink, void* ctx) {
         if (nlev < 2) {  // nothing below the root: the client sends only its handshake
-            sout.submit(0, 0, stream_tag);
+            sout.submit(0, 0, stream_tag, 0, 0, stream_last);
             return 0;
         }
-        const u64 rbase = 0;     // one connection per call: reported starts at 0 (EnumerateQuery.h:19-21)
+        // one connection per prefix: reported starts at 0 (EnumerateQuery.h:19-21); a sub-run of a split prefix continues the count
+        const u64 rbase = stream_rbase;
         for (u32 l = 0; l < nlev; ++l) {
             ARENA_GET(L[l].sz, u64, L[l].n);
             ARENA_GET(L[l].pre, u64, L[l].n);
@@ -2953,7 +2955,13 @@ class Engine {
         }
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
+        // a sub-run of a split prefix leaves out the closing tokens of the first stream_tail_levels nodes of its enforced path
+        std::vector<u64> tail_own(stream_tail_levels < nlev ? stream_tail_levels : nlev - 1, 0);
+        for (size_t l = 0; l < tail_own.size(); ++l) DSM_HIP(hipMemcpyAsync(&tail_own[l], L[l + 1].own, 8, hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
+        u64 tail_bytes = 0;
+        for (u64 o : tail_own) tail_bytes += o - 2;  // (own counts the two opening bytes as well)
+        if (stream_head_skip + tail_bytes > total) return fail(DSM_E_HIP, "split stream: slice larger than the stream");
         int k = 0;
         if (int rc = sout.acquire(total, device, &k)) return rc;  // (waits for the prefix before the previous one to have left the card)
         u8* d_out = sout.buf[k];
@@ -2962,11 +2970,16 @@ class Engine {
                                L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
         DSM_HIP(hipGetLastError());
         DSM_HIP(hipEventRecord(sout.ready[k], st));
-        sout.submit(k, total, stream_tag);
+        sout.submit(k, total, stream_tag, stream_head_skip, total - stream_head_skip - tail_bytes, stream_last);
         return 0;
     }
     StreamOut sout;
-    int stream_tag = 0;  // index of the prefix being enumerated (dsm_miner_enumerate_many)
+    int stream_tag = 0;          // index of the prefix being enumerated (dsm_miner_enumerate_many)
+    // a prefix too large for the buffers goes out as the concatenation of slices of its sub-prefixes' streams (MinerT::stream_auto)
+    u64 stream_rbase = 0;        // nodes reported before this run's subtree in the unsplit stream
+    u64 stream_head_skip = 0;    // leading bytes to leave out (the opening tokens of the enforced path, sent by an earlier sub-run)
+    u32 stream_tail_levels = 0;  // enforced nodes whose closing tokens a later sub-run sends
+    bool stream_last = true;     // the prefix ends with this run
 };
 
 static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
@@ -3014,6 +3027,42 @@ struct MinerT : MinerBase {
         }
         return e.run(prefix.c_str(), ts, nullptr, ctx, emit, lo, k, k + 1, seed);
     }
+    // The wire stream of a prefix whose trie does not fit the device buffers, as the concatenation of slices of its sub-prefixes'
+    // streams.  With p = p1..pk and c1 < .. < cm the bases that continue p,
+    //   stream(p) = open(p1..pk)  [ '(' ci  subtree(p ci)  close(p ci) ]i=1..m  close(pk..p1)
+    // and the run with the enforced path p ci sends open(p1..pk) '(' ci subtree close(p ci) close(pk..p1): the first sub-run is
+    // cut before its closing tokens of pk..p1, the middle ones on both sides, the last one after its 2k opening bytes.  The 'R'
+    // values (nodes reported so far, EnumerateQuery.cpp:214-218) come out right when a sub-run starts counting at the number of
+    // nodes in the subtrees before it -- which also makes the last sub-run's closing tokens of pk..p1 the unsplit stream's.
+    // head_skip / tail_levels: what an enclosing split wants cut from this prefix's stream; *below: nodes of the subtree of p's node.
+    int stream_auto(const std::string& prefix, void* ctx, u64 rbase, u64 head_skip, u32 tail_levels, bool last, u64* below) {
+        const u32 k = (u32)prefix.size();
+        e.stream_rbase = rbase; e.stream_head_skip = head_skip; e.stream_tail_levels = tail_levels; e.stream_last = last;
+        const u64 before = e.stats.reported;
+        int rc = e.run(prefix.c_str(), nullptr, nullptr, ctx, true);
+        if (rc != DSM_E_CAPACITY || k >= 32) {
+            const u64 rep = e.stats.reported - before;            // the enforced path's k nodes and everything below p's node
+            if (below) *below = rep >= k ? rep - k + (k ? 1 : 0) : 0;  // (the root of the empty prefix is not a node of the stream)
+            return rc;
+        }
+        ++e.splits;
+        NodeOrder cap;  // shallow pass: which bases continue p
+        cap.depth = k + 1;
+        rc = e.run(prefix.c_str(), nullptr, nullptr, ctx, false, 1, ~0u, k + 1, nullptr, &cap);
+        if (rc) return rc;
+        u64 sum = 0;
+        const size_t m = cap.sym.size();
+        for (size_t q = 0; q < m; ++q) {
+            u64 sub = 0;
+            rc = stream_auto(prefix + "ACGT"[cap.sym[q]], ctx, rbase + sum, q == 0 ? head_skip : 2ull * k, q + 1 == m ? tail_levels : k,
+                             last && q + 1 == m, &sub);
+            if (rc) return rc;
+            sum += sub;
+        }
+        if (m == 0) return fail(DSM_E_CAPACITY, "device arena exhausted: use a larger arena_bytes");  // (cannot happen: a level overflowed)
+        if (below) *below = sum + (k ? 1 : 0);
+        return 0;
+    }
     // prefixes one after the other on the GPU; the host emits prefix k while prefix k+1 is being expanded
     int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out,
                  dsm_prefix_byte_sink ps = nullptr) override {
@@ -3023,7 +3072,7 @@ struct MinerT : MinerBase {
         for (int k = 0; k < n && !rc; ++k) {
             const bool mine = !e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank;
             e.stream_tag = k;
-            if (e.stream_mode) rc = e.run(prefixes[k], ts, bs, ctx, mine);
+            if (e.stream_mode) rc = stream_auto(prefixes[k] ? prefixes[k] : "", ctx, 0, 0, 0, true, nullptr);
             else rc = run_auto(prefixes[k] ? prefixes[k] : "", ts, ctx, mine, 1, nullptr);
         }
         int rc2 = e.finish_emits();
@@ -3052,18 +3101,11 @@ static int enum_impl(const dsm_index* idx, const char* prefix, u32 fmin, u32 max
     p.prefix = prefix;
     p.fmin = fmin;
     p.maxdepth = maxdepth;
-    std::unique_ptr<Engine<P>> e(new Engine<P>());
+    std::unique_ptr<MinerT<P>> m(new MinerT<P>());
     dsm_index* one = const_cast<dsm_index*>(idx);
-    int rc = e->init(&one, 1, p, true);
-    if (!rc) {
-        e->sout.sink = sink;
-        e->sout.ctx = ctx;
-        rc = e->run(prefix, nullptr, sink, ctx);
-        const int se = e->sout.drain();
-        if (se && !rc) rc = fail(se == 1 ? DSM_E_SINK : DSM_E_HIP, se == 1 ? "byte sink failed" : "copying the wire stream to the host failed");
-    }
-    if (stats) *stats = e->stats;
-    return rc;
+    int rc = m->e.init(&one, 1, p, true);
+    if (rc) return rc;
+    return m->run(prefix, nullptr, sink, ctx, stats);  // (a prefix that does not fit the buffers is sent as slices of its sub-prefixes' streams)
 }
 
 template <typename P>

@@ -215,11 +215,25 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
             assert got == golden.server_out("toy3", "default", p), (arena, p)
             total_splits += st.splits
     assert total_splits > 0
-    # stream mode does not split: it reports the capacity error
-    with pytest.raises(pydsm_mod.DsmError) as e:
-        with pydsm_mod.Miner([idx[0]], fmin=2, stream_mode=True, arena_bytes=2 << 20) as m:
-            m.enumerate("A")
-    assert e.value.code == -28
+    # stream mode splits as well: the stream goes out as slices of the sub-prefixes' streams (R counts carried across them)
+    o = orc.Index(golden.fmi("toy3", names[0]))
+    stream_splits = 0
+    for arena in (2 << 20, 3 << 20, 5 << 20):
+        with pydsm_mod.Miner([idx[0]], fmin=2, stream_mode=True, arena_bytes=arena) as m:
+            for p in ("A", "C", "GT", "TTG", ""):
+                got, st = m.enumerate(p)
+                want = golden.stream("toy3", names[0], p) if p else o.enumerate(names[0], "", fmin=2)[0]
+                assert got == want, (arena, p)
+                stream_splits += st.splits
+            got, st = m.enumerate_many(["T", "G", "C", "A"])
+            assert got == [golden.stream("toy3", names[0], p) for p in ("T", "G", "C", "A")], arena
+    assert stream_splits > 0
+    with pydsm_mod.Miner([idx[0]], fmin=1, maxdepth=40, stream_mode=True, arena_bytes=3 << 20) as m:
+        for p in "ACGT":
+            got, st = m.enumerate(p)
+            assert got == golden.stream("toy3", names[0], p, "fmin1.M40"), p
+            stream_splits += st.splits
+    o.close()
     for ix in idx:
         ix.close()
 
