@@ -3211,6 +3211,129 @@ int dsm_trie_parse(const uint8_t* bytes, size_t n, int device, dsm_trie** out) {
     *out = t.release();
     return DSM_OK;
 }
+// Incremental form of dsm_trie_parse: the bytes of a connection are fed as they arrive; the entries of a level that can no
+// longer change go to the card in windows, so the host holds a window per level instead of the stream (and never the parsed trie).
+struct dsm_trie_stream {
+    struct DevLevel {
+        dsm::u64* freq = nullptr;
+        dsm::u8* pl = nullptr;
+        dsm::u32* fc = nullptr;
+        size_t n = 0, cap = 0;
+    };
+    dsm::StreamParser sp;
+    int device = 0;
+    std::vector<DevLevel> dl;
+    size_t WINDOW = 1u << 16;  // entries of a level collected on the host before they are uploaded (DSM_TRIE_WINDOW: tests use small ones)
+
+    ~dsm_trie_stream() {
+        (void)hipSetDevice(device);
+        for (DevLevel& v : dl) {
+            if (v.freq) (void)hipFree(v.freq);
+            if (v.pl) (void)hipFree(v.pl);
+            if (v.fc) (void)hipFree(v.fc);
+        }
+    }
+    int grow(DevLevel& v, size_t need) {
+        using namespace dsm;
+        if (need <= v.cap) return 0;
+        size_t cap = v.cap ? v.cap * 2 : WINDOW;
+        if (cap < need) cap = need;
+        u64* f = nullptr; u8* p = nullptr; u32* c = nullptr;
+        hipError_t e = hipMalloc((void**)&f, cap * sizeof(u64));
+        if (e == hipSuccess) e = hipMalloc((void**)&p, cap);
+        if (e == hipSuccess) e = hipMalloc((void**)&c, cap * sizeof(u32));
+        if (e == hipSuccess && v.n) {
+            e = hipMemcpy(f, v.freq, v.n * sizeof(u64), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p, v.pl, v.n, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(c, v.fc, v.n * sizeof(u32), hipMemcpyDeviceToDevice);
+        }
+        if (e != hipSuccess) {
+            if (f) (void)hipFree(f);
+            if (p) (void)hipFree(p);
+            if (c) (void)hipFree(c);
+            return fail(DSM_E_NOMEM, std::string("dsm_trie_stream: ") + hipGetErrorString(e));
+        }
+        if (v.freq) (void)hipFree(v.freq);
+        if (v.pl) (void)hipFree(v.pl);
+        if (v.fc) (void)hipFree(v.fc);
+        v.freq = f; v.pl = p; v.fc = c; v.cap = cap;
+        return 0;
+    }
+    // upload what is final of every level (all of it at the end, whole windows otherwise)
+    int flush(bool all) {
+        using namespace dsm;
+        if (dl.size() < sp.L.size()) dl.resize(sp.L.size());
+        for (size_t l = 0; l < sp.L.size(); ++l) {
+            const u64 fin = sp.final_count(l);
+            const size_t k = (size_t)(fin - sp.base[l]);
+            if (k == 0 || (!all && k < WINDOW)) continue;
+            DevLevel& v = dl[l];
+            if (int rc = grow(v, v.n + k)) return rc;
+            const HostTrieLevel& h = sp.L[l];
+            DSM_HIP(hipMemcpy(v.freq + v.n, h.freq.data(), k * sizeof(u64), hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.pl + v.n, h.pl.data(), k, hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.fc + v.n, h.fc.data(), k * sizeof(u32), hipMemcpyHostToDevice));
+            v.n += k;
+            sp.drop_front(l, k);
+        }
+        return 0;
+    }
+};
+
+int dsm_trie_stream_begin(int device, dsm_trie_stream** out) {
+    if (!out) return fail(DSM_E_INVAL, "dsm_trie_stream_begin: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSM_E_NODEV, "dsm_trie_stream_begin: no HIP device");
+    if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_trie_stream_begin: bad device ordinal");
+    dsm_trie_stream* s = new dsm_trie_stream();
+    s->device = device;
+    if (const char* e = getenv("DSM_TRIE_WINDOW")) { const long w = atol(e); if (w > 0) s->WINDOW = (size_t)w; }
+    *out = s;
+    return DSM_OK;
+}
+int dsm_trie_stream_feed(dsm_trie_stream* s, const uint8_t* bytes, size_t n) {
+    if (!s || (!bytes && n)) return fail(DSM_E_INVAL, "dsm_trie_stream_feed: null argument");
+    if (int rc = s->sp.feed(bytes, n, false)) return rc;
+    DSM_HIP(hipSetDevice(s->device));
+    return s->flush(false);
+}
+void dsm_trie_stream_abort(dsm_trie_stream* s) { delete s; }
+int dsm_trie_stream_end(dsm_trie_stream* s, dsm_trie** out) {
+    if (!s || !out) { delete s; return fail(DSM_E_INVAL, "dsm_trie_stream_end: null argument"); }
+    *out = nullptr;
+    std::unique_ptr<dsm_trie_stream> guard(s);
+    if (int rc = s->sp.feed(nullptr, 0, true)) return rc;
+    DSM_HIP(hipSetDevice(s->device));
+    if (int rc = s->flush(true)) return rc;
+    std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
+    t->device = s->device;
+    t->nodes = s->sp.opened;
+    t->maxfreq = s->sp.mf;
+    u64 tot = 0;
+    for (auto& v : s->dl) { t->level_off.push_back(tot); tot += v.n; }
+    t->level_off.push_back(tot);
+    // the levels move into the one allocation the merge reads (device to device; a level's buffers are released as soon as it has moved)
+    DSM_HIP(hipMalloc((void**)&t->d_freq, tot * sizeof(u64)));
+    DSM_HIP(hipMalloc((void**)&t->d_pl, tot));
+    DSM_HIP(hipMalloc((void**)&t->d_fc, tot * sizeof(u32)));
+    for (size_t l = 0; l < s->dl.size(); ++l) {
+        auto& v = s->dl[l];
+        const u64 o = t->level_off[l];
+        if (v.n) {
+            DSM_HIP(hipMemcpy(t->d_freq + o, v.freq, v.n * sizeof(u64), hipMemcpyDeviceToDevice));
+            DSM_HIP(hipMemcpy(t->d_pl + o, v.pl, v.n, hipMemcpyDeviceToDevice));
+            DSM_HIP(hipMemcpy(t->d_fc + o, v.fc, v.n * sizeof(u32), hipMemcpyDeviceToDevice));
+        }
+        if (v.freq) (void)hipFree(v.freq);
+        if (v.pl) (void)hipFree(v.pl);
+        if (v.fc) (void)hipFree(v.fc);
+        v.freq = nullptr; v.pl = nullptr; v.fc = nullptr; v.n = v.cap = 0;
+    }
+    *out = t.release();
+    return DSM_OK;
+}
+
 void dsm_trie_free(dsm_trie* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);

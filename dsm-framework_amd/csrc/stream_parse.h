@@ -1,10 +1,14 @@
 // stream_parse.h -- server-side decode of one client wire stream (host code, no device dependence).
 // TrieReader's token rules (TrieReader.h:32-106: '(' sym ... varint(freq) ['R' varint(count)] leftchar ')', checksum R for
 // depth <= 6) and ServerSocket's varint (ServerSocket.h:45-58), parsed into level arrays in the order the nodes appear
-// = path order inside a level.  Header-only so that the CPU test suite can exercise it without a GPU
+// = path order inside a level.  The decoder is incremental (the reference's server reads its sockets token by token,
+// metaserver.cpp:682-728): bytes are fed in pieces of any size, and the entries of a level that can no longer change -- all but
+// the node still open at that depth -- may be taken away at any time, so a consumer needs memory for a window of every
+// level, not for the stream.  Header-only so that the CPU test suite can exercise it without a GPU
 // (tests/native/stream_parse_check.cpp).
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -22,70 +26,122 @@ struct HostTrieLevel {
     std::vector<u32> fc;
 };
 
-inline int parse_client_stream(const u8* p, size_t n, std::vector<HostTrieLevel>& L, u64* nodes, u64* maxfreq) {
-    L.clear();
-    L.emplace_back();
-    L[0].freq.push_back(0); L[0].pl.push_back(0); L[0].fc.push_back(0);
-    std::vector<u32> stack;  // index of the open node at every depth (stack[0] = root)
-    stack.push_back(0);
-    size_t pos = 0;
+struct StreamParser {
+    // Level l holds the entries [base[l], base[l] + L[l].freq.size()) of that level; earlier ones were taken by the consumer.
+    std::vector<HostTrieLevel> L;
+    std::vector<u64> base;
+    std::vector<u64> stack;   // index (inside its level) of the open node at every depth; stack[0] = the root
+    std::vector<u8> pend;     // bytes of an incomplete token at the end of the previous piece
     u64 opened = 0, mf = 0;
-    auto varint = [&](u64& v) -> bool {  // ServerSocket.h:45-58
-        if (pos >= n) return false;
-        u8 c = p[pos++];
-        if (c >= 0x80) { v = (u64)(c ^ 0x80); return true; }
-        if (c > 8 || pos + c > n) return false;
-        v = 0;
-        for (u8 i = 0; i < c; ++i) v |= (u64)p[pos++] << (8 * i);
-        return true;
-    };
-    while (pos < n) {
-        const size_t depth = stack.size() - 1;
-        if (p[pos] == '(') {
-            if (pos + 1 >= n) return fail(DSM_E_FORMAT, "stream: truncated child");
-            const u8 sym = p[pos + 1];
-            const int k = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : sym == 'T' ? 3 : -1;
-            if (k < 0) return fail(DSM_E_FORMAT, "stream: expecting dna byte");  // TrieReader.h:58-63
-            pos += 2;
-            if (L.size() <= depth + 1) L.emplace_back();
-            HostTrieLevel& me = L[depth + 1];
-            HostTrieLevel& par = L[depth];
-            const u32 pi = stack.back();
-            if ((par.pl[pi] & 15) == 0) par.fc[pi] = (u32)me.freq.size();
-            if ((par.pl[pi] & 15u) >> k) return fail(DSM_E_FORMAT, "stream: children out of order");  // A < C < G < T, each once
-            par.pl[pi] |= (u8)(1u << k);
-            me.freq.push_back(0); me.pl.push_back(0); me.fc.push_back(0);
-            if (me.freq.size() > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "stream: level too wide");
-            stack.push_back((u32)(me.freq.size() - 1));
-            ++opened;
-        } else {
-            if (depth == 0) return fail(DSM_E_FORMAT, "stream: unexpected byte at top level");
-            u64 f = 0;
-            if (!varint(f)) return fail(DSM_E_FORMAT, "stream: bad frequency");
-            if (depth <= 6) {  // TrieReader.h:84-106
-                if (pos >= n || p[pos] != 'R') return fail(DSM_E_FORMAT, "stream: expecting R byte");
-                ++pos;
-                u64 chk = 0;
-                if (!varint(chk)) return fail(DSM_E_FORMAT, "stream: bad checksum");
-                if (chk != opened) return fail(DSM_E_FORMAT, "stream: checksum mismatch");
-            }
-            if (pos + 2 > n) return fail(DSM_E_FORMAT, "stream: truncated close");
-            const u8 lc = p[pos], cl = p[pos + 1];
-            pos += 2;
-            if (cl != ')') return fail(DSM_E_FORMAT, "stream: expecting ) byte");  // TrieReader.h:75-81
-            const int code = lc == '0' ? 0 : lc == 'A' ? 1 : lc == 'C' ? 2 : lc == 'G' ? 3 : lc == 'T' ? 4 : lc == 'N' ? 5 : -1;
-            if (code < 0) return fail(DSM_E_FORMAT, "stream: bad left char");
-            HostTrieLevel& me = L[depth];
-            const u32 mi = stack.back();
-            me.freq[mi] = f;
-            me.pl[mi] |= (u8)(code << 4);
-            mf = f > mf ? f : mf;
-            stack.pop_back();
-        }
+    bool failed = false, finished = false;
+
+    StreamParser() {
+        L.emplace_back();
+        base.push_back(0);
+        L[0].freq.push_back(0); L[0].pl.push_back(0); L[0].fc.push_back(0);
+        stack.push_back(0);
     }
-    if (stack.size() != 1) return fail(DSM_E_FORMAT, "stream: unbalanced parentheses");
-    *nodes = opened;
-    *maxfreq = mf;
+    u64 count(size_t l) const { return base[l] + L[l].freq.size(); }
+    // entries of level l below this index are final (the node open at depth l, if any, is the last one and still collects children)
+    // (the root stays open until the stream ends)
+    u64 final_count(size_t l) const { return !finished && l < stack.size() ? stack[l] : count(l); }
+    // the consumer has copied the first k entries still held of level l
+    void drop_front(size_t l, size_t k) {
+        HostTrieLevel& v = L[l];
+        v.freq.erase(v.freq.begin(), v.freq.begin() + k);
+        v.pl.erase(v.pl.begin(), v.pl.begin() + k);
+        v.fc.erase(v.fc.begin(), v.fc.begin() + k);
+        base[l] += k;
+    }
+
+    // Longest token: varint (9) 'R' varint (9) leftchar ')' = 21 bytes.  Without `last` a piece is parsed up to the point where
+    // fewer than 24 bytes remain; they wait for the next piece.
+    int feed(const u8* b, size_t nb, bool last) {
+        if (failed) return fail(DSM_E_FORMAT, "stream: already failed");
+        const u8* p = b;
+        size_t n = nb;
+        if (!pend.empty()) {  // (rare: only when a token straddles two pieces)
+            pend.insert(pend.end(), b, b + nb);
+            p = pend.data();
+            n = pend.size();
+        }
+        size_t pos = 0;
+        const int rc = parse(p, n, pos, last);
+        if (rc) { failed = true; return rc; }
+        std::vector<u8> rest(p + pos, p + n);
+        pend.swap(rest);
+        if (last && stack.size() != 1) { failed = true; return fail(DSM_E_FORMAT, "stream: unbalanced parentheses"); }
+        if (last) finished = true;
+        return 0;
+    }
+
+private:
+    int parse(const u8* p, size_t n, size_t& pos, bool last) {
+        auto varint = [&](u64& v) -> bool {  // ServerSocket.h:45-58
+            if (pos >= n) return false;
+            u8 c = p[pos++];
+            if (c >= 0x80) { v = (u64)(c ^ 0x80); return true; }
+            if (c > 8 || pos + c > n) return false;
+            v = 0;
+            for (u8 i = 0; i < c; ++i) v |= (u64)p[pos++] << (8 * i);
+            return true;
+        };
+        while (pos < n) {
+            if (!last && n - pos < 24) break;
+            const size_t depth = stack.size() - 1;
+            if (p[pos] == '(') {
+                if (pos + 1 >= n) return fail(DSM_E_FORMAT, "stream: truncated child");
+                const u8 sym = p[pos + 1];
+                const int k = sym == 'A' ? 0 : sym == 'C' ? 1 : sym == 'G' ? 2 : sym == 'T' ? 3 : -1;
+                if (k < 0) return fail(DSM_E_FORMAT, "stream: expecting dna byte");  // TrieReader.h:58-63
+                pos += 2;
+                if (L.size() <= depth + 1) { L.emplace_back(); base.push_back(0); }
+                HostTrieLevel& me = L[depth + 1];
+                HostTrieLevel& par = L[depth];
+                const size_t pi = (size_t)(stack.back() - base[depth]);
+                if ((par.pl[pi] & 15) == 0) par.fc[pi] = (u32)count(depth + 1);
+                if ((par.pl[pi] & 15u) >> k) return fail(DSM_E_FORMAT, "stream: children out of order");  // A < C < G < T, each once
+                par.pl[pi] |= (u8)(1u << k);
+                me.freq.push_back(0); me.pl.push_back(0); me.fc.push_back(0);
+                if (count(depth + 1) > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "stream: level too wide");
+                stack.push_back(count(depth + 1) - 1);
+                ++opened;
+            } else {
+                if (depth == 0) return fail(DSM_E_FORMAT, "stream: unexpected byte at top level");
+                u64 f = 0;
+                if (!varint(f)) return fail(DSM_E_FORMAT, "stream: bad frequency");
+                if (depth <= 6) {  // TrieReader.h:84-106
+                    if (pos >= n || p[pos] != 'R') return fail(DSM_E_FORMAT, "stream: expecting R byte");
+                    ++pos;
+                    u64 chk = 0;
+                    if (!varint(chk)) return fail(DSM_E_FORMAT, "stream: bad checksum");
+                    if (chk != opened) return fail(DSM_E_FORMAT, "stream: checksum mismatch");
+                }
+                if (pos + 2 > n) return fail(DSM_E_FORMAT, "stream: truncated close");
+                const u8 lc = p[pos], cl = p[pos + 1];
+                pos += 2;
+                if (cl != ')') return fail(DSM_E_FORMAT, "stream: expecting ) byte");  // TrieReader.h:75-81
+                const int code = lc == '0' ? 0 : lc == 'A' ? 1 : lc == 'C' ? 2 : lc == 'G' ? 3 : lc == 'T' ? 4 : lc == 'N' ? 5 : -1;
+                if (code < 0) return fail(DSM_E_FORMAT, "stream: bad left char");
+                HostTrieLevel& me = L[depth];
+                const size_t mi = (size_t)(stack.back() - base[depth]);
+                me.freq[mi] = f;
+                me.pl[mi] |= (u8)(code << 4);
+                mf = f > mf ? f : mf;
+                stack.pop_back();
+            }
+        }
+        return 0;
+    }
+};
+
+// the whole stream at once: every level stays on the host
+inline int parse_client_stream(const u8* p, size_t n, std::vector<HostTrieLevel>& L, u64* nodes, u64* maxfreq) {
+    StreamParser sp;
+    if (int rc = sp.feed(p, n, true)) return rc;
+    L.swap(sp.L);
+    *nodes = sp.opened;
+    *maxfreq = sp.mf;
     return 0;
 }
 

@@ -1,7 +1,8 @@
 // metaserver_hip -- drop-in for the reference server (metaserver.cpp:488-815): same options, the expected sample names
 // on stdin, one TCP connection per sample carrying the reference wire protocol, reference-format tuples on stdout.
-// Unmodified reference clients (metaenumerate) can feed it.  Streams are received completely, checked with the
-// reference's token rules (dsm_trie_parse) and merged on the GPU (dsm_merge).
+// Unmodified reference clients (metaenumerate) can feed it.  A reader thread per connection hands the bytes to the library as
+// they arrive (dsm_trie_stream_feed: the reference's token rules and R checksums; what is decoded moves to the card in windows,
+// so the host never holds a stream), and when every stream has ended they are merged on the GPU (dsm_merge).
 //   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] < names.txt
 #include <getopt.h>
 #include <netinet/in.h>
@@ -81,7 +82,6 @@ int main(int argc, char** argv) {
     addr.sin_port = htons(port);
     if (bind(sock, (sockaddr*)&addr, sizeof addr) < 0 || listen(sock, 256) < 0) { std::cerr << "ERROR on binding" << std::endl; return 1; }
 
-    std::vector<std::vector<uint8_t>> streams(d);
     std::vector<bool> seen(d, false);
     std::vector<std::thread> readers;
     std::vector<dsm_trie*> tries(d, nullptr);
@@ -109,21 +109,23 @@ int main(int argc, char** argv) {
         seen[id] = true;
         --pending;
         if (verbose) std::cerr << "new connection id = " << id << ", name = " << name << " (" << pending << " pending)" << std::endl;
-        readers.emplace_back([fd, id, device, &streams, &tries, &perr, &err_mu] {
-            std::vector<uint8_t>& s = streams[id];
+        readers.emplace_back([fd, id, device, &tries, &perr, &err_mu] {
+            // decode while receiving: the streams of the samples are parsed side by side (the decoder is single-threaded per stream)
+            dsm_trie_stream* ts = nullptr;
+            int rc = dsm_trie_stream_begin(device, &ts);
             std::vector<uint8_t> buf(1 << 20);
             for (;;) {
                 ssize_t r = recv(fd, buf.data(), buf.size(), 0);
                 if (r <= 0) break;
-                s.insert(s.end(), buf.begin(), buf.begin() + r);
+                if (!rc) rc = dsm_trie_stream_feed(ts, buf.data(), (size_t)r);  // (after an error the connection is drained, like a reader that gave up)
             }
             close(fd);
-            // decode right here: the streams of the samples are parsed side by side (the decoder is single-threaded per stream)
-            if (dsm_trie_parse(s.data(), s.size(), device, &tries[id])) {
+            if (!rc) { rc = dsm_trie_stream_end(ts, &tries[id]); ts = nullptr; }
+            if (ts) dsm_trie_stream_abort(ts);
+            if (rc) {
                 std::lock_guard<std::mutex> lk(err_mu);
                 if (perr.empty()) perr = std::string(dsm_last_error()) + " (reader " + std::to_string(id) + ")";
             }
-            std::vector<uint8_t>().swap(s);
         });
     }
     for (auto& t : readers) t.join();

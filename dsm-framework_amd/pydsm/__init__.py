@@ -107,6 +107,11 @@ def lib():
         L.dsm_miner_destroy.argtypes = [C.c_void_p]
         L.dsm_trie_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_trie_free.argtypes = [C.c_void_p]
+        L.dsm_trie_stream_begin.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_trie_stream_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.dsm_trie_stream_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dsm_trie_stream_abort.argtypes = [C.c_void_p]
+        L.dsm_trie_stream_abort.restype = None
         L.dsm_trie_nodes.restype = C.c_uint64
         L.dsm_trie_nodes.argtypes = [C.c_void_p]
         L.dsm_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
@@ -406,7 +411,8 @@ class Trie:
     """One client connection's byte stream (what a reference metaenumerate sends), checked and uploaded (TrieReader.h:32-106).
     `stream` may include the b'S' name b'.' handshake; the sample name is then available as .name."""
 
-    def __init__(self, stream, device=0):
+    def __init__(self, stream, device=0, pieces=None):
+        """pieces: feed the body through dsm_trie_stream_* in pieces of these sizes (cycled) instead of dsm_trie_parse."""
         self.name = None
         body = stream
         if stream[:1] == b"S" and b"." in stream:
@@ -414,7 +420,21 @@ class Trie:
             self.name = stream[1:dot].decode(errors="replace")
             body = stream[dot + 1:]
         self.h = C.c_void_p()
-        _check(lib().dsm_trie_parse(body, len(body), device, C.byref(self.h)))
+        if pieces:
+            ts = C.c_void_p()
+            _check(lib().dsm_trie_stream_begin(device, C.byref(ts)))
+            pos, k = 0, 0
+            while pos < len(body):
+                n = pieces[k % len(pieces)]
+                rc = lib().dsm_trie_stream_feed(ts, body[pos:pos + n], min(n, len(body) - pos))
+                if rc:
+                    lib().dsm_trie_stream_abort(ts)
+                    _check(rc)
+                pos += n
+                k += 1
+            _check(lib().dsm_trie_stream_end(ts, C.byref(self.h)))  # (releases the handle, also when it fails)
+        else:
+            _check(lib().dsm_trie_parse(body, len(body), device, C.byref(self.h)))
         self.nodes = lib().dsm_trie_nodes(self.h)
 
     def close(self):

@@ -194,6 +194,15 @@ int dsm_mine(dsm_index* const* idx, int nlocal, const dsm_params* p, dsm_tuple_s
 typedef struct dsm_trie dsm_trie;
 int dsm_trie_parse(const uint8_t* bytes, size_t n, int device, dsm_trie** out);
 void dsm_trie_free(dsm_trie* t);
+/* The same decode fed piece by piece, as the bytes of the connection arrive (the reference's server reads its sockets token by
+ * token while merging, metaserver.cpp:682-728, TrieReader.h:32-106): the library keeps a window of every level on the host and
+ * moves what can no longer change to the card, so the caller never holds a whole stream.  _end checks that the stream is
+ * complete, returns the trie and releases the handle (also when it fails); _abort releases it without a trie. */
+typedef struct dsm_trie_stream dsm_trie_stream;
+int dsm_trie_stream_begin(int device, dsm_trie_stream** out);
+int dsm_trie_stream_feed(dsm_trie_stream* s, const uint8_t* bytes, size_t n);
+int dsm_trie_stream_end(dsm_trie_stream* s, dsm_trie** out);
+void dsm_trie_stream_abort(dsm_trie_stream* s);
 uint64_t dsm_trie_nodes(const dsm_trie* t);
 int dsm_merge(dsm_trie* const* tries, int n, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
 

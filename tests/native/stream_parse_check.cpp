@@ -1,5 +1,5 @@
 // Host-side check of the server-side stream decoder (dsm-framework_amd/csrc/stream_parse.h) without a GPU:
-//   stream_parse_check <file>  ->  "ok nodes=<n> maxfreq=<f> levels=<l> sig=<hash of the level arrays>"  or  "error: <message>"
+//   stream_parse_check <file> [piece]  ->  "ok nodes=<n> maxfreq=<f> levels=<l> sig=<hash of the level arrays>"  or  "error: <message>"
 // The file holds a client stream WITHOUT the 'S' name '.' header (what dsm_trie_parse receives).
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +24,33 @@ int main(int argc, char** argv) {
     fclose(f);
     std::vector<dsm::HostTrieLevel> L;
     dsm::u64 nodes = 0, maxfreq = 0;
-    int rc = dsm::parse_client_stream(buf.data(), buf.size(), L, &nodes, &maxfreq);
+    int rc = 0;
+    const size_t piece = argc > 2 ? (size_t)atol(argv[2]) : 0;
+    if (piece == 0) {
+        rc = dsm::parse_client_stream(buf.data(), buf.size(), L, &nodes, &maxfreq);
+    } else {
+        // the incremental decoder fed `piece` bytes at a time, with a consumer that takes every final entry away after each piece
+        // (the way dsm_trie_stream moves them to the card): the collected levels must equal the one-shot parse
+        dsm::StreamParser sp;
+        auto take = [&]() {
+            if (L.size() < sp.L.size()) L.resize(sp.L.size());
+            for (size_t l = 0; l < sp.L.size(); ++l) {
+                const size_t k = (size_t)(sp.final_count(l) - sp.base[l]);
+                L[l].freq.insert(L[l].freq.end(), sp.L[l].freq.begin(), sp.L[l].freq.begin() + k);
+                L[l].pl.insert(L[l].pl.end(), sp.L[l].pl.begin(), sp.L[l].pl.begin() + k);
+                L[l].fc.insert(L[l].fc.end(), sp.L[l].fc.begin(), sp.L[l].fc.begin() + k);
+                sp.drop_front(l, k);
+            }
+        };
+        for (size_t o = 0; o < buf.size() && !rc; o += piece) {
+            rc = sp.feed(buf.data() + o, buf.size() - o < piece ? buf.size() - o : piece, false);
+            if (!rc) take();
+        }
+        if (!rc) rc = sp.feed(nullptr, 0, true);
+        if (!rc) take();
+        nodes = sp.opened;
+        maxfreq = sp.mf;
+    }
     if (rc) { printf("error: %s\n", g_err.c_str()); return 1; }
     unsigned long long sig = 1469598103934665603ull;  // FNV-1a over (freq, pl, fc) of every node, level by level
     auto mixin = [&](unsigned long long v) { for (int i = 0; i < 8; ++i) { sig ^= (v >> (8 * i)) & 0xFF; sig *= 1099511628211ull; } };

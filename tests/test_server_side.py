@@ -77,6 +77,41 @@ def test_thirty_streams(golden, pydsm_mod):
         ix.close()
 
 
+def test_streams_fed_piece_by_piece_give_the_same_merge(golden, pydsm_mod):
+    """dsm_trie_stream_begin/feed/end (what metaserver_hip's reader threads call while the bytes arrive): pieces of one byte, of
+    sizes around the decoder's look-ahead and of sizes that make windows of a level go to the card before the stream ends."""
+    m = golden.manifest["sets"]["toy3"]
+    names = m["names"]
+    for p, pieces in (("A", [1]), ("C", [23, 24, 25, 7]), ("G", [4096]), ("T", [100000, 3])):
+        tries = [pydsm_mod.Trie(golden.stream("toy3", n, p), pieces=pieces) for n in names]
+        whole = [pydsm_mod.Trie(golden.stream("toy3", n, p)) for n in names]
+        assert [t.nodes for t in tries] == [t.nodes for t in whole]
+        got, st = pydsm_mod.merge(tries, emax=2.0)
+        assert got == golden.server_out("toy3", "default", p), (p, pieces)
+        for t in tries + whole:
+            t.close()
+    empty = pydsm_mod.Trie(b"Stoy-9.", pieces=[5])
+    assert empty.nodes == 0
+    empty.close()
+    # small upload windows, so that parts of a level leave the host (and the card's level buffers grow) while the stream comes in
+    os.environ["DSM_TRIE_WINDOW"] = "48"
+    try:
+        for p, pieces in (("A", [1000]), ("GT", [37])):
+            tries = [pydsm_mod.Trie(golden.stream("toy3", n, p), pieces=pieces) for n in names]
+            got, _ = pydsm_mod.merge(tries, emax=2.0)
+            assert got == golden.server_out("toy3", "default", p), (p, pieces)
+            for t in tries:
+                t.close()
+    finally:
+        del os.environ["DSM_TRIE_WINDOW"]
+    s = golden.stream("toy3", "toy-1", "C")
+    body = s[s.index(b".") + 1:]
+    for bad in (body[:-1], body.replace(b"(C(A", b"(C(X", 1), body + b")", bytes([body[0], body[1]]) + body[4:]):
+        for pieces in ([1], [24], [5000]):
+            with pytest.raises(pydsm_mod.DsmError):
+                pydsm_mod.Trie(bad, pieces=pieces)
+
+
 def test_corrupt_streams_are_rejected(golden, pydsm_mod):
     s = golden.stream("toy3", "toy-1", "C")
     body = s[s.index(b".") + 1:]

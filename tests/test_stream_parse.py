@@ -18,10 +18,10 @@ def exe(tmp_path_factory):
     return out
 
 
-def _run(exe, tmp_path, body):
+def _run(exe, tmp_path, body, piece=0):
     p = tmp_path / "s.bin"
     p.write_bytes(body)
-    r = subprocess.run([exe, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([exe, str(p)] + ([str(piece)] if piece else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return r.returncode, r.stdout.decode().strip(), r.stderr.decode()
 
 
@@ -63,3 +63,22 @@ def test_damaged_streams_are_rejected(golden, exe, tmp_path):
         rc, out, err = _run(exe, tmp_path, bad)
         assert rc == 1 and out.startswith("error:"), (out, err)
         assert "AddressSanitizer" not in err and "runtime error" not in err
+
+
+def test_incremental_decode_equals_the_one_shot_parse(golden, exe, tmp_path):
+    """The decoder fed in pieces (1 byte, sizes around its 24-byte look-ahead, larger ones), its final entries taken away
+    after every piece (what dsm_trie_stream does on the way to the card): same level arrays as parsing the whole stream."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    for name, prefix in ((names[0], "A"), (names[1], "GT"), (names[2], "ACGTACGTACGT")):
+        body = _body(golden.stream("toy3", name, prefix))
+        rc, whole, err = _run(exe, tmp_path, body)
+        assert rc == 0, err
+        for piece in (1, 7, 23, 24, 25, 64, 1000, 65536):
+            rc, out, err = _run(exe, tmp_path, body, piece)
+            assert rc == 0 and out == whole, (name, prefix, piece, out, err)
+    body = _body(golden.stream("toy3", names[0], "GT"))
+    i = body.index(b"R")
+    for bad in (body[:-1], body[: len(body) // 2], body[:i + 1] + bytes([body[i + 1] ^ 1]) + body[i + 2:], body.replace(b"(G", b"(X", 1)):
+        for piece in (1, 24, 4096):
+            rc, out, _ = _run(exe, tmp_path, bad, piece)
+            assert rc == 1 and out.startswith("error:"), (piece, out)
