@@ -209,6 +209,11 @@ struct ExpandArgs {
     u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
     u32 access_pack;  // BitRank::rank calls of getL by 3-bit code, four bits each (a table in the argument block would be a load)
     u64 costsum_lo, costsum_hi;  // sum of cost[c] over the bases of a 4-bit set, six bits per set: sets 0-9, sets 10-15
+    // A launch queued before the host knows the level (single sample): width and frequency class of the level come from two device
+    // words the previous level's publish kernel wrote; the launch does nothing when the class is not the one the host assumed
+    // (formats are launch-time choices) or the level does not fit -- the host then sees the same words and launches again.
+    const u32* dyn;    // null: F, nbp and the formats above are final
+    u32 dyn_expect, dyn_mask, fcap;
 };
 
 __device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
@@ -634,6 +639,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) =
                                                      unsigned long long* __restrict__ childmax) {
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
+    if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
+        const u32 F = a.dyn[0], cls = a.dyn[1];
+        if ((cls & a.dyn_mask) != a.dyn_expect || F > a.fcap || F == 0) return;
+        a.F = F;
+        a.nbp = (F + TILE - 1) / TILE;
+        if (a.w16 != 2) pl = reinterpret_cast<u8*>(valf) + (size_t)F * (a.w16 ? 2u : (u32)sizeof(P));  // one sample: the flag bytes follow its frequencies
+        if (a.nbp <= 1) cnt = nullptr;
+    }
     expand_sweep<P, ONESB, INC, OUTC>(ix, sbl, parked, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
 }
 
@@ -861,6 +874,7 @@ struct PublishArgs {
     u64 cmax_bpr;
     u32 cmax_world;
     u32* clear;           // header of the message the next level's expand kernels will fill (4 words), may be null
+    u32* next;            // device copy of the new level's width and frequency class for an expand launch queued ahead (may be null)
     uint4* packet;        // pinned, 16-byte aligned
     u32 seq;
 };
@@ -877,6 +891,7 @@ __global__ void publish_kernel(PublishArgs a) {
     __syncthreads();
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
+        if (a.next) { a.next[0] = tot; a.next[1] = wide; }
         *a.packet = make_uint4(a.seq, tot | ((wide & 1u) << 31) | ((wide >> 1) << 30), (u32)cand, (u32)(cand >> 32));  // one global_store_dwordx4
     }
 }
@@ -2032,6 +2047,8 @@ class Engine {
     u32** d_rp_tab[2] = {nullptr, nullptr};  // device copies of rp[k][*], tpos[*] and splane[*] for the advance kernel
     u32** d_tpos_tab = nullptr;
     u64** d_splane_tab = nullptr;
+    bool spec_mode = false;     // single sample: the next level's LF-step launch is queued before the host has seen the level (see ExpandArgs::dyn)
+    u32* d_dyn = nullptr;       // [0] width [1] frequency class of the level the last publish kernel announced
     bool pack_columns = true;   // levels whose frequencies are all below 512: one 16-bit column word per node (DSM_PACK=0 turns it off)
     bool batch_mode = true;     // several samples: one launch per level for up to BATCH_MAX of this process's, handles derived in the kernel
     bool self_mode = false;     // = several samples, index mode, batch_mode: no handle tables (see expand_tile, SELF)
@@ -2133,6 +2150,9 @@ class Engine {
         DSM_HIP(hipMemGetInfo(&free_b, &total_b));
         if (const char* e = getenv("DSM_BATCH")) batch_mode = atoi(e) != 0;
         if (const char* e = getenv("DSM_PACK")) pack_columns = atoi(e) != 0;
+        spec_mode = d == 1 && !trie_mode && !multi;
+        if (const char* e = getenv("DSM_SPEC")) spec_mode = spec_mode && atoi(e) != 0;
+        if (spec_mode) { if (int rc = dalloc(d_dyn, (size_t)4)) return rc; }
         self_mode = d > 1 && !trie_mode && batch_mode;
         // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
         // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
@@ -2411,7 +2431,8 @@ class Engine {
         // the host to get through them.
         const bool trace_levels = getenv("DSM_TRACE_LEVELS") != nullptr;  // debugging aid: widths of the levels on stderr
         bool fmt_in = false;  // format of the records of the level about to be expanded (the root's record is wide)
-        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, bool w9, const u32* lslot) -> int {
+        // dynamic: F is not known yet (0 is passed): the kernel takes the width from d_dyn and runs only if the level's class is (w16, w9)
+        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, bool w9, const u32* lslot, bool fmt_in, bool dynamic) -> int {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
             const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
@@ -2424,6 +2445,12 @@ class Engine {
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
             ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w9 ? 2u : (w16 ? 1u : 0u);
+            if (dynamic) {
+                ea.dyn = d_dyn;
+                ea.dyn_mask = pack_columns ? 3u : 1u;
+                ea.dyn_expect = ((w16 ? 0u : 1u) | (w9 ? 0u : 2u)) & ea.dyn_mask;
+                ea.fcap = Fcap;
+            }
             unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send);  // header, cleared by the previous level's publish kernel
             if (depth < prefix.size()) {
                 const char* q = strchr(bases, prefix[depth]);
@@ -2513,8 +2540,8 @@ class Engine {
                 const bool one_sb = (m.n >> SB_SHIFT) == 0;
                 P* cf = reinterpret_cast<P*>(es.valf);
                 u8* cl = es.pl;
-                const dim3 eg(need < expand_blocks ? need : expand_blocks);
-                u32* ecnt = (d == 1 && ea.nbp > 1) ? cntraw : (u32*)nullptr;
+                const dim3 eg(dynamic ? expand_blocks : (need < expand_blocks ? need : expand_blocks));
+                u32* ecnt = (d == 1 && (ea.nbp > 1 || dynamic)) ? cntraw : (u32*)nullptr;
 #define DSM_LAUNCH_EXPAND(SB, IC, OC)                                                                                               \
     hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], \
                        ecnt, cf, cl, ea, d_counters, d_childmax)
@@ -2523,7 +2550,6 @@ class Engine {
 #undef DSM_FORMATS
                 ++stats.expand_launches;
             }
-            fmt_in = w16 && !trie_mode;  // the next level's records
             DSM_HIP(hipEventRecord(ea1, st));
             if (device < 16) { g_expand_chain.last[device] = ea1; g_expand_chain.owner[device] = this; }
             chain_lock.unlock();
@@ -2531,7 +2557,8 @@ class Engine {
             return 0;
         };
         DSM_HIP(hipMemsetAsync(multi ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
-        if (int rc = launch_expand(F, depth, cur, xcur, w16, w9, L[0].slot)) return rc;
+        if (int rc = launch_expand(F, depth, cur, xcur, w16, w9, L[0].slot, fmt_in, false)) return rc;
+        fmt_in = w16 && !trie_mode;  // the next level's records are compact iff this level is narrow
         while (true) {
             const u64 slots = (u64)F * 4;
             const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
@@ -2611,8 +2638,14 @@ class Engine {
                 if (filtered) pa.cand = d_totals64;
                 pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 pa.packet = reinterpret_cast<uint4*>(h_totals + 304); pa.seq = ++pub_seq;
+                pa.next = spec_mode ? d_dyn : nullptr;
                 hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, pa);
             }
+            // ---- the next level's LF-step launch goes out now, sized on the device, assuming the level is of this level's frequency
+            // class (the largest frequency only falls with depth: a prefix changes class twice); the host catches up below ----
+            const bool spec = spec_mode;
+            const bool spec_w16 = w16, spec_w9 = w9;
+            if (spec) { if (int rc = launch_expand(0, depth + 1, nxt, xcur ^ 1, spec_w16, spec_w9, new_slot2, fmt_in, true)) return rc; }
             u32 pk[4];
             {   // the publish kernel is the last work queued: its packet in pinned memory is this level's completion.  Spinning on
                 // it returns a few microseconds after the store; a stream synchronisation wakes the thread later.
@@ -2632,6 +2665,9 @@ class Engine {
             const u32 Fn = pk[1] & 0x3FFFFFFFu;
             w16 = !(pk[1] >> 31) && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
             w9 = w16 && !((pk[1] >> 30) & 1u) && pack_columns;  // ... and nine: frequency and flags share a 16-bit word
+            // did the launch queued ahead run?  (the kernel tested the same two words the packet carries)
+            const bool spec_hit = spec && Fn > 0 && Fn <= Fcap && w16 == spec_w16 && (!pack_columns || ((pk[1] >> 30) & 1u) == (spec_w9 ? 0u : 1u));
+            if (spec && !spec_hit) --stats.expand_launches;  // (the launch queued ahead found no level, or another class, and did nothing)
             h_totals[300] = pk[2]; h_totals[301] = pk[3];  // candidate totals of this level (read by emit_store)
             if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             // commit the provisional window at its real size
@@ -2640,7 +2676,13 @@ class Engine {
             if (Fn) {
                 child.slot = arena.get<u32>(Fn);  // same address as new_slot2
                 if (int rc = alloc_kids(child)) return rc;
-                if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16, w9, child.slot)) return rc;  // w16, w9 already describe the next level
+                if (spec_hit) {
+                    stats.expand_slots += Fn;
+                    stats.expand_column_bytes += (u64)Fn * (w9 ? 2u : (w16 ? 3u : (u32)sizeof(P) + 1));
+                } else {
+                    if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16, w9, child.slot, fmt_in, false)) return rc;  // w16, w9 already describe the next level
+                }
+                fmt_in = w16 && !trie_mode;
                 // orders are only needed by a rank that emits this prefix (and by the shallow pass that captures them)
                 if (!(emit || capture)) {}
                 else if (order_mode == 1)
