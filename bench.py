@@ -304,13 +304,39 @@ def main():
     nlanes = max(1, min(nlanes, len(prefixes)))
     lanes = []
     gate = None
+    # The exchange itself: by default the library's own (dsm_rccl_*: one RCCL communicator per lane, ncclAllGather from the C
+    # callback on the lane's stream, no Python per level; torch.distributed only carries the ids and the timing barrier).
+    # DSM_BENCH_EXCHANGE=torch (and every non-nccl backend, e.g. gloo rehearsals with several ranks on one card) goes through
+    # pydsm.dist.Exchange = torch.distributed.all_gather_into_tensor from a Python callback.
+    native = (world > 1 or forced) and dist.get_backend() == "nccl" and os.environ.get("DSM_BENCH_EXCHANGE", "rccl") == "rccl"
     if (world > 1 or forced) and nlanes > 1:
-        from pydsm.dist import TurnGate
-        gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
+        if native:
+            gate = pydsm.RcclGate(nlanes)
+        else:
+            from pydsm.dist import TurnGate
+            gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
     for j in range(nlanes):
         lane = {"prefixes": prefixes[j::nlanes], "stream": torch.cuda.Stream(device=dev) if nlanes > 1 else torch.cuda.current_stream()}
         allgather = exchange = None
-        if world > 1 or forced:
+        if native:
+            try:
+                ids = [pydsm.RcclComm.unique_id() if rank == 0 else None]
+            except pydsm.DsmError as e:  # librccl could not be loaded: the same on every rank of a node
+                ids = [None]
+                print("bench.py: native exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            if ids[0] is None:
+                native = False
+                if gate is not None:
+                    from pydsm.dist import TurnGate
+                    gate = TurnGate(nlanes)
+            else:
+                lane["rccl"] = pydsm.RcclComm(ids[0], world, rank, local)  # collective over the ranks
+                allgather = lane["rccl"]
+        if native:
+            pass
+        elif world > 1 or forced:
             from pydsm.dist import Exchange
             group = None  # the default communicator, shared by the lanes
             lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
@@ -327,8 +353,11 @@ def main():
                                     stream_mode=args.stream_mode)
         lanes.append(lane)
     if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
-        for ln in lanes:
-            ln["ex"].gate = gate
+        for j, ln in enumerate(lanes):
+            if native:
+                ln["rccl"].attach_gate(gate, j)
+            else:
+                ln["ex"].gate = gate
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
            "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0}
@@ -396,7 +425,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and gate is not None:
+    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and gate is not None and not native:
         def dump_order():
             with open(os.path.join(ROOT, "gpurun_out", "order_rank%d.txt" % rank), "w") as f:
                 for it in gate.log:
@@ -407,7 +436,7 @@ def main():
         _t = _th.Timer(100, dump_order)
         _t.daemon = True
         _t.start()
-    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1:
+    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and not native:
         import atexit
         atexit.register(lambda: print("TRACE rank %d: %s" % (rank, lanes[0]["ex"].trace[:60]), file=sys.stderr, flush=True))
     for _ in range(args.warmup):
@@ -457,7 +486,10 @@ def main():
                                    "fmin=%d Emax=%g pmin=%d pmax=%d%s%s, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin,
                                                                               args.pmax, ", 64-bit positions" if args.wide else "",
                                                                               ", wire-stream mode" if args.stream_mode else "", len(prefixes)),
-                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes)},
+                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes),
+                       "exchange": ("none (single process)" if not (world > 1 or forced) else
+                                    "dsm_rccl: ncclAllGather from the library's callback, one communicator per lane" if native else
+                                    "torch.distributed all_gather_into_tensor (%s) from a Python callback" % dist.get_backend())},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          # `achieved` = bytes the kernel itself counted / HIP-event time of its launches (live, this run).
                          # `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes of the same command (offline profile,

@@ -107,6 +107,18 @@ def lib():
         L.dsm_miner_destroy.argtypes = [C.c_void_p]
         L.dsm_trie_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_trie_free.argtypes = [C.c_void_p]
+        L.dsm_rccl_unique_id.argtypes = [C.c_void_p]
+        L.dsm_rccl_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_rccl_attach_gate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.dsm_rccl_destroy.argtypes = [C.c_void_p]
+        L.dsm_rccl_destroy.restype = None
+        L.dsm_rccl_gate_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        for fn in (L.dsm_rccl_gate_begin, L.dsm_rccl_gate_retire):
+            fn.argtypes = [C.c_void_p, C.c_int]
+            fn.restype = None
+        for fn in (L.dsm_rccl_gate_reset, L.dsm_rccl_gate_destroy):
+            fn.argtypes = [C.c_void_p]
+            fn.restype = None
         L.dsm_trie_stream_begin.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_trie_stream_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.dsm_trie_stream_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -241,7 +253,11 @@ def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, r
     p.wide = wide
     p.emit_owner_only = emit_owner_only
     p.stream = stream
-    if allgather is not None:
+    if isinstance(allgather, RcclComm):  # the library's own RCCL exchange: a C function and its context, no Python per level
+        p.allgather = C.cast(lib().dsm_rccl_allgather, ALLGATHER)
+        p.allgather_ctx = allgather.h
+        keep.append(allgather)
+    elif allgather is not None:
         def _ag(ctx, s, r, n, st):
             try:
                 allgather(s, r, n, st)
@@ -256,6 +272,60 @@ def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, r
     if exchange is not None:
         p.exchange_send, p.exchange_recv, p.exchange_bytes = exchange
     return p
+
+
+class RcclGate:
+    """Turn-taking of the prefix lanes of one process (dsm_rccl_gate): their collectives are enqueued in the same order on
+    every rank.  begin(lane) / retire(lane) around a lane's run, reset() between runs."""
+
+    def __init__(self, nlanes):
+        self.h = C.c_void_p()
+        _check(lib().dsm_rccl_gate_create(nlanes, C.byref(self.h)))
+
+    def begin(self, lane):
+        lib().dsm_rccl_gate_begin(self.h, lane)
+
+    def retire(self, lane):
+        lib().dsm_rccl_gate_retire(self.h, lane)
+
+    def reset(self):
+        lib().dsm_rccl_gate_reset(self.h)
+
+    def close(self):
+        if self.h:
+            lib().dsm_rccl_gate_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class RcclComm:
+    """One RCCL communicator of the library's native exchange (dsm_rccl_*): pass it as `allgather=` to Miner / mine.
+    Rank 0 makes the id with RcclComm.unique_id() and the host carries it to the other ranks (128 bytes, any channel);
+    creating the communicator is collective over its ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib().dsm_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid, world_size, rank, device=0):
+        if len(uid) != 128:
+            raise ValueError("an RCCL id has 128 bytes")
+        self.h = C.c_void_p()
+        self.gate = None
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _check(lib().dsm_rccl_create(buf, world_size, rank, device, C.byref(self.h)))
+
+    def attach_gate(self, gate, lane):
+        """From now on this communicator's collectives wait for their lane's turn (call it once the miners of all lanes exist:
+        their creation runs collectives one lane after the other)."""
+        _check(lib().dsm_rccl_attach_gate(self.h, gate.h if gate is not None else None, lane))
+        self.gate = gate
+
+    def close(self):
+        if self.h:
+            lib().dsm_rccl_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def _tuple_sink(out, text, on_batch, err):

@@ -156,6 +156,27 @@ typedef int (*dsm_tuple_sink)(void* ctx, const dsm_tuple_batch* batch);
  * pointers; must be ordered after prior work on `stream` and before later work on it. */
 typedef int (*dsm_allgather_fn)(void* ctx, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
 
+/* A ready-made dsm_allgather_fn over RCCL for hosts with one process per GPU (bench.py under torch.distributed.run, MPI):
+ * ncclAllGather on the engine's stream straight from the library's per-level callback (metaenumerate.cpp:268-309 fans out over
+ * sockets; this is its replacement between GPUs).  librccl is loaded at run time; the host carries the id from rank 0 to the
+ * others (any channel) and passes dsm_rccl_allgather with the dsm_rccl* as allgather_ctx.  Several prefix lanes of a process
+ * take one communicator each and share a gate, which makes them enqueue their collectives in the same order on every rank:
+ * begin(lane) before and retire(lane) after a lane's run, reset between runs.  (A miner's creation runs collectives too: create
+ * the miners one after the other, in the same order on every rank, and attach the gate afterwards.) */
+#define DSM_RCCL_ID_BYTES 128
+typedef struct dsm_rccl dsm_rccl;
+typedef struct dsm_rccl_gate dsm_rccl_gate;
+int dsm_rccl_unique_id(uint8_t* id /* DSM_RCCL_ID_BYTES */);
+int dsm_rccl_create(const uint8_t* id, int world_size, int rank, int device, dsm_rccl** out);
+int dsm_rccl_attach_gate(dsm_rccl* c, dsm_rccl_gate* gate /* NULL detaches */, int lane);  /* after the miners of all lanes exist */
+int dsm_rccl_allgather(void* comm, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
+void dsm_rccl_destroy(dsm_rccl* c);
+int dsm_rccl_gate_create(int nlanes, dsm_rccl_gate** out);
+void dsm_rccl_gate_begin(dsm_rccl_gate* g, int lane);
+void dsm_rccl_gate_retire(dsm_rccl_gate* g, int lane);
+void dsm_rccl_gate_reset(dsm_rccl_gate* g);
+void dsm_rccl_gate_destroy(dsm_rccl_gate* g);
+
 typedef struct dsm_params {
     const char* prefix;      /* enforced path (hostinfo third column, metaenumerate.cpp:216); "" = whole trie */
     uint32_t fmin;           /* metaenumerate --fmin (default 10, metaenumerate.cpp:141) */

@@ -234,19 +234,24 @@ def test_rccl_exchange_from_two_lane_threads_single_rank():
 
 @pytest.mark.gpu
 def test_bench_forced_exchange_rehearsal_on_rccl(tmp_path):
-    """bench.py --force-exchange: one rank drives the complete N > 1 path (send buffer, one RCCL all-gather per level through
-    torch.distributed, two lane threads under the turn gate, capacity agreement, per-prefix status words, owner-only emission)
-    and must report exactly the nodes and tuples of the plain single-rank run."""
+    """bench.py --force-exchange: one rank drives the complete N > 1 path (send buffer, one RCCL all-gather per level, two lane
+    threads under the turn gate, capacity agreement, per-prefix status words, owner-only emission) with both exchanges and must
+    report exactly the nodes and tuples of the plain single-rank run."""
     import json
     import subprocess
     env = dict(os.environ, DSM_BENCH_DIR=str(tmp_path))
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--reads", "200000", "--genome", "1000000"]
     outs = []
-    for extra in ([], ["--force-exchange"]):
-        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+    # plain; the library's own RCCL exchange (dsm_rccl_*: ncclAllGather from the C callback, two communicators under the native
+    # gate); the torch.distributed exchange (Python callback, one communicator under the TurnGate)
+    for extra, ex in (([], None), (["--force-exchange"], "rccl"), (["--force-exchange"], "torch")):
+        r = subprocess.run(base + extra, env=dict(env, DSM_BENCH_EXCHANGE=ex) if ex else env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
-    a, b = outs
+    a, b, c = outs
+    assert b["config"]["exchange"].startswith("dsm_rccl") and c["config"]["exchange"].startswith("torch.distributed")
+    for k in ("rank0_nodes_per_step", "tuples_per_step", "union_nodes_per_step", "candidates_per_step", "rank_ops_per_node"):
+        assert a["detail"][k] == c["detail"][k], k
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline"):            # the driver's contract for the JSON line
         assert k in a, k
