@@ -263,3 +263,24 @@ def test_bench_forced_exchange_rehearsal_on_rccl(tmp_path):
     assert b["config"]["parallelism"].endswith("2 prefix lane(s) per GPU")
     for k in ("rank0_nodes_per_step", "tuples_per_step", "union_nodes_per_step", "candidates_per_step", "rank_ops_per_node"):
         assert a["detail"][k] == b["detail"][k], k
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_card_over_gloo(tmp_path):
+    """The driver's N > 1 launch line on the one card a test box has: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2` with DSM_BENCH_BACKEND=gloo (two RCCL ranks cannot share a card): two samples, one per rank, one all-gather per level,
+    two prefix lanes per rank.  Rank 0 prints one JSON line; its aggregate node count is the sum of both ranks' own nodes."""
+    import json
+    import subprocess
+    env = dict(os.environ, DSM_BENCH_DIR=str(tmp_path), DSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu",
+           "--reads", "200000", "--genome", "1000000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["exchange"].startswith("torch.distributed") and "2 prefix lane(s)" in d["config"]["parallelism"]
+    assert d["detail"]["union_nodes_per_step"] > d["detail"]["rank0_nodes_per_step"] > 0   # two samples: the union trie is larger than one sample's
