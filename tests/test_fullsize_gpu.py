@@ -91,6 +91,27 @@ def test_whole_pass_invariants(big):
     assert sst.reported == gst.reported and nb > 4 * sst.reported
 
 
+def test_split_wire_stream_at_full_size(big):
+    """Stream mode with buffers far too small for a one-letter prefix of the full-size index: the prefix goes out as slices of
+    its sub-prefixes' streams (several levels of splitting) and the bytes equal the unsplit run's -- which, restricted to the
+    same depth, equal the oracle's."""
+    import hashlib
+    import orc
+    pydsm, ix, path, reads = big
+    with pydsm.Miner([ix], fmin=10, maxdepth=13, stream_mode=True) as sm:
+        whole, st0 = sm.enumerate("C")
+    assert st0.splits == 0 and len(whole) > 50_000_000
+    with pydsm.Miner([ix], fmin=10, maxdepth=13, stream_mode=True, arena_bytes=96 << 20) as sm:
+        parts, st1 = sm.enumerate("C")
+        many, _ = sm.enumerate_many(["T", "C"])
+    assert st1.splits >= 4
+    assert hashlib.sha256(parts).digest() == hashlib.sha256(whole).digest() and many[1] == whole
+    o = orc.Index(path)
+    want, _ = o.enumerate(ix.name, "C", fmin=10, maxdepth=13)
+    o.close()
+    assert whole == want
+
+
 def test_three_midsize_samples_against_oracle():
     """d = 3 at a size where the top levels need wide frequency columns and the rest 16-bit ones (the toy fixtures never
     leave the 16-bit regime): GPU tuples == oracle's on whole one-letter prefixes restricted by maxdepth, and on deep 7-mers."""
