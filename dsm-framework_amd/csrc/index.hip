@@ -255,7 +255,7 @@ struct StagePool {
     int ensure() {
         for (int t = 0; t < THREADS; ++t)
             for (int k = 0; k < 2; ++k)
-                if (!buf[t][k] && hipHostMalloc(&buf[t][k], CHUNK) != hipSuccess) return fail(DSM_E_NOMEM, "hipHostMalloc (index staging) failed");
+                if (!buf[t][k] && hipHostMalloc(&buf[t][k], CHUNK, hipHostMallocPortable) != hipSuccess) return fail(DSM_E_NOMEM, "hipHostMalloc (index staging) failed");
         return 0;
     }
 };
