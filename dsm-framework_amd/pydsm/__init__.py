@@ -413,7 +413,7 @@ class Miner:
             body = b"S" + self.indexes[0].name.encode() + b"." + body
         return body, st
 
-    def enumerate_many(self, prefixes, with_header=True, discard=False):
+    def enumerate_many(self, prefixes, with_header=True, discard=False, on_piece=None):
         """dsm_miner_enumerate_many: the wire streams of several prefixes, the bytes of one crossing PCIe while the GPU works
         on the next.  -> ([bytes per prefix] or [byte counts] with discard, stats summed over the prefixes)"""
         chunks = [[] for _ in prefixes]
@@ -427,7 +427,9 @@ class Miner:
                     done.append(k)
                     return 0
                 nbytes[k] += n
-                if not discard:
+                if on_piece is not None:
+                    on_piece(k, C.string_at(p, n))
+                elif not discard:
                     chunks[k].append(C.string_at(p, n))
                 return 0
             except BaseException as e:  # noqa: BLE001 - must not unwind through C
@@ -440,7 +442,7 @@ class Miner:
         _check_sink(lib().dsm_miner_enumerate_many(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
         if done != list(range(len(prefixes))):
             raise DsmError("dsm_miner_enumerate_many: prefixes completed as %r" % (done,))
-        if discard:
+        if discard or on_piece is not None:
             return nbytes, st
         head = (b"S" + self.indexes[0].name.encode() + b".") if with_header else b""
         return [head + b"".join(c) for c in chunks], st

@@ -201,6 +201,18 @@ def test_persistent_miner_reuses_buffers(golden, pydsm_mod):
         sizes, _ = m.enumerate_many(ps, discard=True)
         assert sizes == [len(g) - len(head) for g in got]
         assert m.enumerate_many([])[0] == []
+        # a sink that fails: the call reports it (the remaining prefixes are dropped) and the miner stays usable
+        seen = []
+
+        def failing(k, piece):
+            seen.append(k)
+            if k == 1:
+                raise RuntimeError("sink full")
+        with pytest.raises(RuntimeError):
+            m.enumerate_many(["A", "C", "G", "T"], on_piece=failing)
+        assert seen and max(seen) == 1
+        got, _ = m.enumerate_many(["G", "T"])
+        assert got == [golden.stream("toy3", names[1], p) for p in ("G", "T")]
     with pytest.raises(pydsm_mod.DsmError):
         pydsm_mod.Miner(idx, stream_mode=True)
     # an arena too small for the frontier buffers is refused at creation
