@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -201,7 +202,7 @@ struct ExpandArgs {
     u32 nbp;          // tiles of the level = stride of cnt4
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
-    u32 symbol_phase; // 1: node is handled by nextSymbol (size-1 nodes take followOneBranch)
+    u32 symbol_phase; // bit 0: node is handled by nextSymbol (size-1 nodes take followOneBranch); bit 1: the children count as reported
     u32 w16;          // this level's column: 0 = frequencies as P plus a flag byte; 1 = 16-bit frequencies plus a flag byte (every
                       // frequency of the level is below 65535); 2 = ONE 16-bit word per node, frequency in bits 0-8 and the flags
                       // in bits 9-15 (every frequency below 512: all but the top levels of a prefix)
@@ -440,7 +441,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
         staged_blk(wl, idx1, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
-        const bool single = a.symbol_phase && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
+        const bool single = (a.symbol_phase & 1u) && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -568,7 +569,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             pl[i] = (u8)(present | (mycode << 4));
         }
     }
-    acc.kne += k; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
+    acc.kne += (a.symbol_phase & 2u) ? k : 0u; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
     // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
     // when in use) and its children's (compact word each, or their fields; rb_out collected by the rounds)
     acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
@@ -690,9 +691,9 @@ constexpr u32 XHDR = 16;  // every rank's message starts with the largest child 
 // each waits for the previously issued expand of the process on that device, so two LF-step kernels never run side by
 // side (their per-launch durations stay meaningful) while everything else of one lane overlaps the other lane's expand.
 struct ExpandChain {
+    struct Link { hipEvent_t last = nullptr; const void* owner = nullptr; };  // completion of the most recently issued expand launch
     std::mutex mu;
-    hipEvent_t last[16] = {nullptr};   // per device: completion of the most recently issued expand launch
-    const void* owner[16] = {nullptr};
+    std::map<int, Link> dev;           // per device ordinal
 };
 static ExpandChain g_expand_chain;
 
@@ -1805,6 +1806,7 @@ struct StreamOut {
     bool stop = false, started = false;
     int err = 0;  // 1: sink failed, 2: HIP error
     int device = 0, next = 0;
+    int inflight = 0;  // jobs submitted and not yet delivered (an end-of-prefix job without bytes holds no buffer, but its sink call counts)
     dsm_byte_sink sink = nullptr;
     dsm_prefix_byte_sink psink = nullptr;
     void* ctx = nullptr;
@@ -1847,6 +1849,7 @@ struct StreamOut {
                 if (rc && !err) err = rc;
                 if (!rc) delivered += j.len;
                 if (j.total) busy[j.k] = false;
+                --inflight;
             }
             cv.notify_all();
         }
@@ -1879,13 +1882,14 @@ struct StreamOut {
             std::lock_guard<std::mutex> lk(mu);
             if (!started) { started = true; th = std::thread([this] { loop(); }); }
             if (total) { busy[k] = true; next = k ^ 1; }
+            ++inflight;
             q.push_back(Job{k, total, tag, off, len, last});
         }
         cv.notify_all();
     }
     int drain() {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return q.empty() && !busy[0] && !busy[1]; });
+        cv.wait(lk, [&] { return inflight == 0; });
         const int e = err;
         err = 0;
         return e;
@@ -2088,8 +2092,8 @@ class Engine {
         if (ev1) (void)hipEventDestroy(ev1);
         {   // nobody may wait on an event of this engine any more
             std::lock_guard<std::mutex> lk(g_expand_chain.mu);
-            for (int dv = 0; dv < 16; ++dv)
-                if (g_expand_chain.owner[dv] == this) { g_expand_chain.owner[dv] = nullptr; g_expand_chain.last[dv] = nullptr; }
+            for (auto& kv : g_expand_chain.dev)
+                if (kv.second.owner == this) kv.second = ExpandChain::Link();
         }
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -2342,7 +2346,7 @@ class Engine {
         std::vector<std::vector<u16>> ord;  // capture: their orders; seed: ord[0]
     };
     int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx, bool emit = true, u32 emit_lo = 1,
-            u32 emit_hi = ~0u, u32 expand_cap = ~0u, const NodeOrder* seed = nullptr, NodeOrder* capture = nullptr) {
+            u32 emit_hi = ~0u, u32 expand_cap = ~0u, const NodeOrder* seed = nullptr, NodeOrder* capture = nullptr, bool count = true) {
         const std::string prefix = prefix_c ? prefix_c : "";
         for (char ch : prefix)
             if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
@@ -2460,11 +2464,13 @@ class Engine {
                 ea.allowed = (depth >= prm.maxdepth || depth >= expand_cap) ? 0u : 15u;  // EnumerateQuery.cpp:153
                 ea.symbol_phase = 1;
             }
+            // `reported` counts a node once however a prefix was split: a run counts the depths it is responsible for
+            if (count && depth + 1 >= emit_lo && depth + 1 <= emit_hi) ea.symbol_phase |= 2u;
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
-            if (device < 16 && g_expand_chain.last[device] && g_expand_chain.owner[device] != this)
-                DSM_HIP(hipStreamWaitEvent(st, g_expand_chain.last[device], 0));
+            ExpandChain::Link& link = g_expand_chain.dev[device];
+            if (link.last && link.owner != this) DSM_HIP(hipStreamWaitEvent(st, link.last, 0));
             DSM_HIP(hipEventRecord(ea0, st));
             for (int s = 0; s < nlocal && trie_mode; ++s) {  // children, frequency and left char come from the parsed stream
                 const dsm_trie* t = tries[s];
@@ -2551,7 +2557,7 @@ class Engine {
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
-            if (device < 16) { g_expand_chain.last[device] = ea1; g_expand_chain.owner[device] = this; }
+            link.last = ea1; link.owner = this;
             chain_lock.unlock();
             DSM_HIP(hipGetLastError());
             return 0;
@@ -3033,6 +3039,7 @@ static bool need_wide(dsm_index* const* idx, int n, const dsm_params* p) {
 
 struct MinerBase {
     virtual ~MinerBase() {}
+    virtual bool stream_mode() const = 0;
     virtual int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) = 0;
     virtual int run_many(const char* const* prefixes, int n, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out,
                          dsm_prefix_byte_sink ps = nullptr) = 0;
@@ -3040,6 +3047,7 @@ struct MinerBase {
 template <typename P>
 struct MinerT : MinerBase {
     Engine<P> e;
+    bool stream_mode() const override { return e.stream_mode; }
     int run(const char* prefix, dsm_tuple_sink ts, dsm_byte_sink bs, void* ctx, dsm_stats* out) override {
         const char* one[1] = {prefix};
         return run_many(one, 1, ts, bs, ctx, out);
@@ -3048,7 +3056,8 @@ struct MinerT : MinerBase {
     // The four sub-prefixes emit everything deeper than the prefix itself; a shallow pass (children of the prefix only)
     // then emits the prefix node and its ancestors, whose predicates need all four children (metaserver.cpp:416-417).
     // Post-order is preserved: descendants first, in A,C,G,T order.  Collective-safe: every rank sees the same failure
-    // only if capacities agree, so ranks must use equal arena sizes.  (reported / union_nodes count the enforced path
+    // only if capacities agree, so ranks must use equal arena sizes.  (`reported` counts every node once: a run counts the depths it
+    // emits, the shallow pass none; union_nodes and the cost counters still count the enforced path
     // once per sub-run in that case.)
     typedef typename Engine<P>::NodeOrder NodeOrder;
     int run_auto(const std::string& prefix, dsm_tuple_sink ts, void* ctx, bool emit, u32 lo, const NodeOrder* seed) {
@@ -3058,7 +3067,7 @@ struct MinerT : MinerBase {
         const u32 k = (u32)prefix.size();
         NodeOrder cap;  // shallow pass: the children of the prefix node with all four siblings visible -> their orders
         cap.depth = k + 1;
-        rc = e.run(prefix.c_str(), ts, nullptr, ctx, false, lo, ~0u, k + 1, seed, &cap);
+        rc = e.run(prefix.c_str(), ts, nullptr, ctx, false, lo, ~0u, k + 1, seed, &cap, false);
         if (rc) return rc;
         for (size_t q = 0; q < cap.sym.size(); ++q) {
             NodeOrder sub;
@@ -3103,6 +3112,7 @@ struct MinerT : MinerBase {
         }
         if (m == 0) return fail(DSM_E_CAPACITY, "device arena exhausted: use a larger arena_bytes");  // (cannot happen: a level overflowed)
         if (below) *below = sum + (k ? 1 : 0);
+        e.stats.reported = before + k + sum;  // what the unsplit run would have counted: the enforced path once, every node below it once
         return 0;
     }
     // prefixes one after the other on the GPU; the host emits prefix k while prefix k+1 is being expanded
@@ -3206,20 +3216,29 @@ int dsm_miner_create(dsm_index* const* idx, int nlocal, const dsm_params* p, int
     *out = reinterpret_cast<dsm_miner*>(m);
     return DSM_OK;
 }
+// a miner is created for tuples or for the wire stream (dsm_miner_create's stream_mode): the other kind of entry point is refused
+static int mode_check(dsm_miner* m, bool want_stream, const char* fn) {
+    if (!m) return fail(DSM_E_INVAL, std::string(fn) + ": null miner");
+    if (reinterpret_cast<MinerBase*>(m)->stream_mode() != want_stream)
+        return fail(DSM_E_INVAL, std::string(fn) + (want_stream ? ": the miner was not created with stream_mode" : ": the miner was created with stream_mode"));
+    return 0;
+}
 int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
-    if (!m) return fail(DSM_E_INVAL, "null miner");
+    if (int rc = mode_check(m, false, "dsm_miner_mine")) return rc;
     return reinterpret_cast<MinerBase*>(m)->run(prefix, sink, nullptr, ctx, stats);
 }
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats) {
-    if (!m) return fail(DSM_E_INVAL, "null miner");
+    if (int rc = mode_check(m, true, "dsm_miner_enumerate")) return rc;
     return reinterpret_cast<MinerBase*>(m)->run(prefix, nullptr, sink, ctx, stats);
 }
 int dsm_miner_enumerate_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_prefix_byte_sink sink, void* ctx, dsm_stats* stats) {
     if (!m || !prefixes || nprefix < 0) return fail(DSM_E_INVAL, "dsm_miner_enumerate_many: bad arguments");
+    if (int rc = mode_check(m, true, "dsm_miner_enumerate_many")) return rc;
     return reinterpret_cast<MinerBase*>(m)->run_many(prefixes, nprefix, nullptr, nullptr, ctx, stats, sink);
 }
 int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats) {
     if (!m || !prefixes || nprefix < 0) return fail(DSM_E_INVAL, "dsm_miner_mine_many: bad arguments");
+    if (int rc = mode_check(m, false, "dsm_miner_mine_many")) return rc;
     return reinterpret_cast<MinerBase*>(m)->run_many(prefixes, nprefix, sink, nullptr, ctx, stats);
 }
 void dsm_miner_destroy(dsm_miner* m) { delete reinterpret_cast<MinerBase*>(m); }

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +44,20 @@ static int to_file(void* ctx, const dsm_tuple_batch* b) {
 }
 
 // ---- several devices ---------------------------------------------------------------------------------------------------
+// The rank threads meet once between opening their indexes and creating their miners (whose first step is a collective): a rank
+// that could not open an index tells the others there, and nobody enters a collective that a missing rank would leave hanging.
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    int expected = 0, arrived = 0;
+    std::atomic<int> failed{0};
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (++arrived == expected) cv.notify_all();
+        else cv.wait(lk, [&] { return arrived == expected; });
+    }
+};
+
 struct Rank {
     int rank = 0, world = 1, device = 0;
     ncclComm_t comm = nullptr;
@@ -52,6 +68,7 @@ struct Rank {
     dsm_params p;
     std::string err;
     dsm_stats st;
+    Rendezvous* meet = nullptr;
 };
 
 // dsm_allgather_fn: every rank contributes `bytes` bytes, receives world * bytes, rank-major; ordered on the engine's stream
@@ -91,10 +108,17 @@ static void run_rank(Rank* r) {
         if (dsm_index_open(f.c_str(), r->device, &ix)) { fail(f + ": " + dsm_last_error()); break; }
         idx.push_back(ix);
     }
-    // Every rank must reach the collectives of miner creation, or the others hang: a rank that failed above still cannot take
-    // part without its indexes, so the whole job is aborted by the caller when any rank reports an error before this point.
+    if (!r->err.empty()) r->meet->failed.store(1);
+    r->meet->arrive_and_wait();
+    // Past this point every rank is inside collectives (miner creation agrees on capacities, mining gathers every level): a rank
+    // that fails alone cannot be waited for by the others, so such a failure ends the process (the message goes out first).
+    auto fatal = [&](const std::string& msg) {
+        std::cerr << "dsm_node: device " << r->device << ": " << msg << std::endl;
+        fflush(nullptr);
+        _exit(1);
+    };
     dsm_miner* m = nullptr;
-    if (r->err.empty()) {
+    if (!r->meet->failed.load()) {
         dsm_params p = r->p;
         p.world_size = (uint32_t)r->world;
         p.rank = (uint32_t)r->rank;
@@ -102,12 +126,12 @@ static void run_rank(Rank* r) {
         p.allgather_ctx = r;
         p.emit_owner_only = 1;
         p.stream = r->stream;
-        if (dsm_miner_create(idx.data(), (int)idx.size(), &p, 0, &m)) fail(std::string("miner: ") + dsm_last_error());
+        if (dsm_miner_create(idx.data(), (int)idx.size(), &p, 0, &m)) fatal(std::string("miner: ") + dsm_last_error());
     }
     if (m) {
         std::vector<const char*> pre;
         for (const std::string& s : *r->prefixes) pre.push_back(s.c_str());
-        if (dsm_miner_mine_many(m, pre.data(), (int)pre.size(), to_prefix_text, r, &r->st)) fail(std::string("mine: ") + dsm_last_error());
+        if (dsm_miner_mine_many(m, pre.data(), (int)pre.size(), to_prefix_text, r, &r->st)) fatal(std::string("mine: ") + dsm_last_error());
         dsm_miner_destroy(m);
     }
     for (auto* ix : idx) dsm_index_close(ix);
@@ -119,11 +143,27 @@ static int run_devices(const std::vector<int>& devs, const dsm_params& p, const 
     const int G = (int)devs.size();
     if (files.size() % G) { std::cerr << "dsm_node: the number of samples must be a multiple of the number of devices" << std::endl; return 1; }
     const size_t nlocal = files.size() / G;
+    // A batch is routed to its prefix by its first path (to_prefix_text), which is only unambiguous when no prefix continues
+    // another one; the reference runs one server per prefix of one length (wrapper-SLURM/example-server.sh:27-41).
+    for (size_t a = 0; a < prefixes.size(); ++a)
+        for (size_t b = 0; b < prefixes.size(); ++b)
+            if (a != b && prefixes[b].compare(0, prefixes[a].size(), prefixes[a]) == 0) {
+                std::cerr << "dsm_node: --devices needs prefixes none of which starts with another (" << prefixes[a] << ", " << prefixes[b] << ")" << std::endl;
+                return 1;
+            }
+    for (const std::string& f : files) {  // unreadable files are reported before any device or communicator is touched
+        FILE* t = fopen(f.c_str(), "rb");
+        if (!t) { std::cerr << "dsm_node: cannot read " << f << std::endl; return 1; }
+        fclose(t);
+    }
     std::vector<ncclComm_t> comms(G);
     if (ncclCommInitAll(comms.data(), G, devs.data()) != ncclSuccess) { std::cerr << "dsm_node: ncclCommInitAll failed" << std::endl; return 1; }
     std::vector<std::string> out(prefixes.size());
     std::vector<Rank> ranks(G);
+    Rendezvous meet;
+    meet.expected = G;
     for (int r = 0; r < G; ++r) {
+        ranks[r].meet = &meet;
         ranks[r].rank = r; ranks[r].world = G; ranks[r].device = devs[r]; ranks[r].comm = comms[r];
         ranks[r].files.assign(files.begin() + r * nlocal, files.begin() + (r + 1) * nlocal);
         ranks[r].prefixes = &prefixes; ranks[r].out = &out; ranks[r].p = p;
