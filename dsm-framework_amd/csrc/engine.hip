@@ -833,8 +833,23 @@ __device__ __forceinline__ bool filter_node(const FilterArgs& a, const Xchg& x, 
     return true;
 }
 
+// Path words (mining): every node keeps the last (up to 16) symbols of its path, two bits each, and the index of its ancestor at the
+// level where that chunk starts -- level 16 * ((l - 1) / 16) for a node of level l.  A child's word follows from its parent's in the
+// advance sweep (the lane of parent u reads word u, coalesced), and the path of a candidate of level l is put together from
+// (l + 15) / 16 words instead of l parent links: one random 64-byte line per 16 symbols instead of one per symbol.
+constexpr u32 PW_CHUNK = 16;
+__device__ __forceinline__ uint2 child_path_word(const uint2 parent, u32 u, u32 plevel, u32 c) {
+    const u32 r = plevel & (PW_CHUNK - 1);
+    return r == 0 ? make_uint2(u, c) : make_uint2(parent.x, parent.y | (c << (2 * r)));
+}
+
 struct AdvanceOut {
-    u32* slot;        // retained: 4*parent + sym of every new node
+    u32* slot;        // retained: 4*parent + sym of every new node (null: nobody reads the links -- mining without derived handles)
+    uint2* pw;        // retained path words of the new nodes (null: stream mode); pw_after_slot: they follow the slot array, whose length
+    const uint2* parent_pw;  // (the new level's width) only the device knows when this sweep runs -- *width, or the single tile's total
+    const u32* width;
+    u32 pw_after_slot;
+    u32 plevel;       // level of the parents
     u16* nT;          // per new node
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
@@ -951,6 +966,8 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
     }
     if (lane < 4) o.kcum[wv * 4 + lane] = DSM_PICK(cum, lane);
     if (o.cnt_clear && threadIdx.x < 4) o.cnt_clear[(size_t)threadIdx.x * o.nbp + blockIdx.x] = 0;  // the expand kernels of the next level add into it
+    uint2* pw = o.pw;
+    if (o.pw_after_slot) pw = reinterpret_cast<uint2*>(reinterpret_cast<u8*>(o.slot) + (((size_t)total * 4 + 255) & ~(size_t)255));
     if (u < F) {
         u32 pres = 0, lastT = 0, vj[4];
 #pragma unroll
@@ -960,10 +977,13 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
         }
         const u32 nc = __popc(pres);
         if (!o.single) o.samechild[u] = (nc == 1 && lastT == o.parent_nT[u]) ? 1 : 0;  // (a single sample: always 1 reader, nobody reads these)
+        uint2 mypw = make_uint2(0u, 0u);
+        if (pw) mypw = o.parent_pw[u];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (((pres >> c) & 1u) && vj[c] < o.cap) {  // a level wider than its arrays is reported through the total, not written
-                o.slot[vj[c]] = 4u * u + (u32)c;
+                if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
+                if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
                 if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
             }
         }
@@ -1007,6 +1027,8 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
     const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
     const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const u64 lt = (1ull << lane) - 1;
+    uint2* pw = o.pw;
+    if (o.pw_after_slot) pw = reinterpret_cast<uint2*>(reinterpret_cast<u8*>(o.slot) + (((size_t)o.width[0] * 4 + 255) & ~(size_t)255));
 #pragma unroll
     for (int it = 0; it < NPT; ++it) {
         const u32 w = w0 + (u32)it * stride;
@@ -1055,10 +1077,13 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
         }
         if (u >= F) continue;
         if (!o.single) o.samechild[u] = (u8)same;
+        uint2 mypw = make_uint2(0u, 0u);
+        if (pw) mypw = o.parent_pw[u];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (((pres >> c) & 1u) && vj[c] < o.cap) {
-                o.slot[vj[c]] = 4u * u + (u32)c;
+                if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
+                if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
                 if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
             }
         }
@@ -1380,7 +1405,7 @@ __global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, c
 }
 
 struct LevelDev {
-    const u32* slot;
+    const uint2* pw;    // path words of the level's nodes (see AdvanceOut)
     const u32* cand_node;
     const u32* cand_poff;
     const u32* crank;   // post-order rank of candidate k
@@ -1399,19 +1424,23 @@ __global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ pat
     if (c <= cbs.n) { out[2 * c] = path_off[cbs.tb[c]]; out[2 * c + 1] = pair_off[cbs.tb[c]]; }
 }
 
-// Paths and pairs of all tuples.  Threads take the candidates level by level in node order: the nodes of neighbouring lanes
-// are neighbours in their level, and so are their ancestors all the way up (children with the same symbol keep the order of
-// their parents), so every step of the walk reads neighbouring links.  A lane gathers four symbols before it stores them.
+// Paths and pairs of all tuples.  Threads take the candidates level by level in node order.  A path is put together from the path
+// words of the node and of its ancestors at the chunk boundaries (levels 16, 32, ...): 16 symbols per dependent load.
 __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const LevelDev* __restrict__ lv, const u32* __restrict__ path_off,
                                                          const u32* __restrict__ pair_off, char* __restrict__ paths, u32* __restrict__ ids,
                                                          u64* __restrict__ freqs) {
-    // the per-level link arrays and candidate bases are read at every step of every walk: kept in LDS (a step is then ONE dependent
-    // global load, the link itself)
+    // the per-level arrays and candidate bases are read by every walk: kept in LDS, with the text of every byte of four symbols
     constexpr u32 LDS_LEVELS = 1024;
-    __shared__ const u32* s_slot[LDS_LEVELS];
+    __shared__ const uint2* s_pw[LDS_LEVELS];
     __shared__ u32 s_cbase[LDS_LEVELS];
+    __shared__ u32 s_text[256];
     const u32 nl = nlev < LDS_LEVELS ? nlev : LDS_LEVELS;
-    for (u32 q = threadIdx.x; q < nl; q += blockDim.x) { s_slot[q] = lv[q].slot; s_cbase[q] = lv[q].cbase; }
+    for (u32 q = threadIdx.x; q < nl; q += blockDim.x) { s_pw[q] = lv[q].pw; s_cbase[q] = lv[q].cbase; }
+    {
+        const u32 b = threadIdx.x;  // (256 threads: one table entry each) "ACGT"[sym], the first symbol in the lowest byte
+        s_text[b] = ((0x54474341u >> (8 * (b & 3))) & 0xFFu) | (((0x54474341u >> (8 * ((b >> 2) & 3))) & 0xFFu) << 8) |
+                    (((0x54474341u >> (8 * ((b >> 4) & 3))) & 0xFFu) << 16) | (((0x54474341u >> (8 * ((b >> 6) & 3))) & 0xFFu) << 24);
+    }
     __syncthreads();
     const u32 f = blockIdx.x * blockDim.x + threadIdx.x;  // candidates in level-major order
     if (f >= nt) return;
@@ -1430,17 +1459,26 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
     for (u32 q = b; q < e; ++q, ++o) { ids[o] = L.ids[q]; freqs[o] = L.freqs[q]; }
     u32 v = L.cand_node[k];
     char* dst = paths + path_off[r];
-    u32 word = 0, have = 0;
-    for (u32 l = lvl; l >= 1; --l) {
-        const u32 sl = (l < LDS_LEVELS ? s_slot[l] : lv[l].slot)[v];
-        word = (word << 8) | ((0x54474341u >> (8 * (sl & 3))) & 0xFFu);  // "ACGT"[sym]: the lowest character so far goes to the lowest byte
-        v = sl >> 2;
-        if (++have == 4) {
-            __builtin_memcpy(dst + l - 1, &word, 4);
-            have = 0;
+    u32 l = lvl;
+    while (l > 0) {
+        const u32 first = ((l - 1) / PW_CHUNK) * PW_CHUNK;  // path position of the chunk's first symbol = level of the ancestor it hangs from
+        const uint2 w = (l < LDS_LEVELS ? s_pw[l] : lv[l].pw)[v];
+        const u32 cnt = l - first;  // 1..16 symbols; only a path's last chunk is a partial one
+        const u32 q0 = s_text[w.y & 0xFFu], q1 = s_text[(w.y >> 8) & 0xFFu], q2 = s_text[(w.y >> 16) & 0xFFu], q3 = s_text[w.y >> 24];
+        char* d = dst + first;
+        if (cnt == PW_CHUNK) {
+            __builtin_memcpy(d, &q0, 4); __builtin_memcpy(d + 4, &q1, 4); __builtin_memcpy(d + 8, &q2, 4); __builtin_memcpy(d + 12, &q3, 4);
+        } else {
+            const u32 full = cnt >> 2;
+            if (full > 0) __builtin_memcpy(d, &q0, 4);
+            if (full > 1) __builtin_memcpy(d + 4, &q1, 4);
+            if (full > 2) __builtin_memcpy(d + 8, &q2, 4);
+            const u32 tail = full == 0 ? q0 : (full == 1 ? q1 : (full == 2 ? q2 : q3));
+            for (u32 q = 0; q < (cnt & 3u); ++q) d[4 * full + q] = (char)(tail >> (8 * q));
         }
+        v = w.x;
+        l = first;
     }
-    for (u32 q = 0; q < have; ++q) dst[q] = (char)(word >> (8 * q));
 }
 
 // ---- wire stream (ClientSocket.h:20-39) ---------------------------------------------------------
@@ -1518,7 +1556,8 @@ struct Arena {
 
 struct LevelHost {
     u32 n = 0;
-    u32* slot = nullptr;        // 4 * parent + sym
+    u32* slot = nullptr;        // 4 * parent + sym (stream mode, derived handles; null otherwise)
+    uint2* pw = nullptr;        // path words (mining)
     u64* kplane = nullptr;      // children directory (struct Kids): 4 planes and 4 counts per 64 nodes, whole tiles
     u32* kcum = nullptr;
     Kids kids() const { Kids k; k.plane = kplane; k.cum = kcum; return k; }
@@ -2400,8 +2439,10 @@ class Engine {
             LevelHost root;
             root.n = 1;
             ARENA_GET(root.slot, u32, 1);
+            ARENA_GET(root.pw, uint2, 1);
             if (int rc = alloc_kids(root)) return rc;
             if (self_mode) DSM_HIP(hipMemsetAsync(root.slot, 0, sizeof(u32), st));
+            DSM_HIP(hipMemsetAsync(root.pw, 0, sizeof(uint2), st));
             L.push_back(root);
             u16 rootT = (u16)d;
             DSM_HIP(hipMemcpyAsync(nT[0], &rootT, sizeof(u16), hipMemcpyHostToDevice, st));
@@ -2598,12 +2639,24 @@ class Engine {
                 else filtered = true;
             }
             const size_t mark2 = arena.off;
-            u32* new_slot2 = arena.get<u32>((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
-            if (!new_slot2) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
+            // What a level retains per node: the links (4 * parent + symbol) where something reads them -- the wire stream, handles
+            // derived inside the LF-step kernel -- and the path words when tuples are mined.  With both, the words follow the links,
+            // whose length only the device knows when the sweep runs: the window is sized for the widest level possible here.
+            const bool keep_slot = stream_mode || self_mode, keep_pw = !stream_mode;
+            const size_t wcap = (size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap;
+            u8* window = arena.get<u8>(wcap * ((keep_slot ? 4 : 0) + (keep_pw ? 8 : 0)) + 512);
+            if (!window) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
+            u32* new_slot2 = keep_slot ? reinterpret_cast<u32*>(window) : nullptr;
             const u32 nbp = (F + TILE - 1) / TILE;  // tiles of this level
             AdvanceOut ao;
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.nT = nT[nxt]; ao.samechild = samechild;
+            if (keep_pw) {
+                ao.pw = reinterpret_cast<uint2*>(window);  // (behind the links: the kernels place it, see pw_after_slot)
+                ao.pw_after_slot = keep_slot ? 1u : 0u;
+                ao.parent_pw = me.pw;
+                ao.plevel = depth;
+            }
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
             ao.seg = Seg;
@@ -2614,6 +2667,7 @@ class Engine {
             ao.splane = d_splane_tab;
             ao.rp_index = self_mode ? 0u : 1u;
             ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp;
+            ao.width = d_totals;  // (levels of several tiles: the scan's grand total)
             const bool merged = d > 1 || trie_mode;  // the union of several columns (a parsed stream is treated alike)
             if (merged && nbp == 1) {  // a single tile evaluates the columns itself
                 ao.eval = 1; ao.kplane_w = me.kplane;
@@ -2680,7 +2734,8 @@ class Engine {
             arena.off = mark2;
             child.n = Fn;
             if (Fn) {
-                child.slot = arena.get<u32>(Fn);  // same address as new_slot2
+                if (keep_slot) child.slot = arena.get<u32>(Fn);   // same address as new_slot2
+                if (keep_pw) child.pw = arena.get<uint2>(Fn);     // the window's start, or right behind the links (256-byte granules, as the kernels assume)
                 if (int rc = alloc_kids(child)) return rc;
                 if (spec_hit) {
                     stats.expand_slots += Fn;
@@ -2711,7 +2766,13 @@ class Engine {
             if (Fn && capture && depth + 1 == capture->depth) {
                 std::vector<u32> hs(Fn);
                 std::vector<u16> hn(Fn);
-                DSM_HIP(hipMemcpyAsync(hs.data(), child.slot, (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
+                if (child.slot) DSM_HIP(hipMemcpyAsync(hs.data(), child.slot, (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
+                else {  // the last symbol of the node's path word
+                    std::vector<uint2> hp(Fn);
+                    DSM_HIP(hipMemcpyAsync(hp.data(), child.pw, (size_t)Fn * sizeof(uint2), hipMemcpyDeviceToHost, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                    for (u32 v = 0; v < Fn; ++v) hs[v] = (hp[v].y >> (2 * (depth % PW_CHUNK))) & 3u;
+                }
                 DSM_HIP(hipMemcpyAsync(hn.data(), nT[nxt], (size_t)Fn * sizeof(u16), hipMemcpyDeviceToHost, st));
                 DSM_HIP(hipStreamSynchronize(st));
                 capture->sym.clear();
@@ -2875,7 +2936,7 @@ class Engine {
         std::vector<LevelDev> lv(nlev);
         u32 cb = 0;
         for (u32 l = 0; l < nlev; ++l) {
-            lv[l].slot = L[l].slot; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff; lv[l].crank = crank[l];
+            lv[l].pw = L[l].pw; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff; lv[l].crank = crank[l];
             lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = l ? L[l].ncand : 0; lv[l].npairs = L[l].npairs;
             lv[l].cbase = cb;
             cb += lv[l].ncand;
