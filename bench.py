@@ -116,7 +116,7 @@ def cpu_baseline_reference(path, args, ix, pydsm):
     """The UNMODIFIED reference client (oracle/_ref/metaenumerate, built from /root/reference by oracle/Makefile.ref; it travels to
     the GPU box as a binary) on a bounded sample of the same workload: one thread and one TCP connection per 6-mer prefix
     (metaenumerate.cpp:268-309), the connections drained by local sinks.  Timed from the first connection to the last close, i.e.
-    without the index load; the node count of those prefixes comes from the GPU run of the same prefixes (outputs are identical)."""
+    without the index load; the node count is taken from the bytes the reference sent (parsed after the timed region)."""
     import random
     import socket
     import subprocess
@@ -136,18 +136,20 @@ def cpu_baseline_reference(path, args, ix, pydsm):
     port = srv.getsockname()[1]
     tm = {"first": None, "last": None, "bytes": 0}
     lock = threading.Lock()
+    streams = []  # what the reference client sent, connection by connection (parsed after the clock has stopped)
 
     def drain(c):
-        n = 0
+        parts = []
         while True:
             b = c.recv(1 << 20)
             if not b:
                 break
-            n += len(b)
+            parts.append(b)
         c.close()
         with lock:
             tm["last"] = time.time()
-            tm["bytes"] += n
+            tm["bytes"] += sum(len(b) for b in parts)
+            streams.append(parts)
 
     def acceptor():
         ths = []
@@ -172,8 +174,13 @@ def cpu_baseline_reference(path, args, ix, pydsm):
     if r.returncode != 0 or tm["first"] is None:
         return None
     dt = tm["last"] - tm["first"]
-    with pydsm.Miner([ix], fmin=args.fmin, stream_mode=True) as m:
-        nodes = sum(m.enumerate(p, discard=True)[1].reported for p in prefixes)
+    # the node count comes from the reference's OWN bytes: every connection's stream goes through the library's stream parser
+    # (TrieReader's token rules, 'R' checksums verified), which counts the '(' tokens (EnumerateQuery.cpp:207-209)
+    nodes = 0
+    for parts in streams:
+        t = pydsm.Trie(b"".join(parts), device=ix.device if hasattr(ix, "device") else 0)
+        nodes += t.nodes
+        t.close()
     return {"value": nodes / dt, "unit": "substrings/s", "cores": cores, "kind": "reference", "host_cpus": os.cpu_count(),
             "sample": "the unmodified reference metaenumerate (oracle/_ref) on %d random 6-mer prefixes of 4096 of the same index, one thread "
                       "and one TCP connection per prefix into local sinks, %d nodes (%.0f MB of stream) in %.1f s from first connection to "
@@ -199,10 +206,28 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
                 "tuples": st.tuples, "union_nodes": st.union_nodes, "expand_ms": st.expand_ms, "device_ms": st.device_ms,
                 "splits": st.splits}
 
+    def note(msg):
+        print("bench: extra records: " + msg, file=sys.stderr, flush=True)
+
     try:
         out.append(dict(one([ix], "same workload with 64-bit positions (wide=1)", pmin=pmin, wide=1), dtype="u64"))
     except Exception as e:  # noqa: BLE001
         out.append({"record": "64-bit positions", "error": repr(e)})
+    note("64-bit positions done")
+    try:  # the literal metaenumerate replacement: the wire stream of every prefix, through PCIe into a sink (EnumerateQuery.cpp:207-222)
+        with pydsm.Miner([ix], fmin=args.fmin, stream=torch.cuda.current_stream().cuda_stream, stream_mode=True) as m:
+            m.enumerate_many(prefixes, discard=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nbs, st = m.enumerate_many(prefixes, discard=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out.append({"record": "same workload as wire streams (stream mode: the client's bytes to a host sink)", "value": st.reported / dt,
+                    "unit": "substrings/s", "ms_per_step": dt * 1e3, "nodes": st.reported, "wire_bytes": int(sum(nbs)),
+                    "expand_ms": st.expand_ms, "device_ms": st.device_ms, "splits": st.splits, "dtype": "u32"})
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "wire-stream mode", "error": repr(e)})
+    note("wire-stream mode done")
     try:
         a8 = argparse.Namespace(**vars(args))
         a8.gpus, a8.nlocal = 1, 8
@@ -219,25 +244,47 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
             x.close()
     except Exception as e:  # noqa: BLE001
         out.append({"record": "8 samples on one GPU", "error": repr(e)})
-    try:  # BASELINE configs[3]'s sample size: one 4-Gbase read set (n = 8.08e9 > 2^32), a real BWT built here by dsm_bwt_build
+    try:  # BASELINE configs[3]: 4-Gbase read sets (n = 8.08e9 > 2^32, real BWTs built here by dsm_bwt_build), first one alone, then
+        # its one-card share: EIGHT of them resident (8 x 4 GB of index), d = 8, -P 2 --pmax 8
         from pydsm import builder
         big = 4 * args.reads
-        pth = os.path.join(args.workdir, "sample-4g.s4242_r%d_l%d_g%d.fmi" % (big, args.rlen, 4 * args.genome))
+        nbig = int(os.environ.get("DSM_BENCH_BIG_SAMPLES", "8"))
+        bpaths = []
         t0 = time.time()
-        if not os.path.exists(pth):
-            codes = builder.synth_reads(4242, big, args.rlen, 4 * args.genome, args.sub_rate, device=dev)
-            builder.build_from_codes(codes, pth + ".tmp")
-            del codes
-            torch.cuda.empty_cache()
-            os.replace(pth + ".tmp", pth)
+        for k in range(nbig):  # (the files tests/test_fullsize_gpu.py::test_real_bwt_beyond_2_32 builds: shared when both run on one box)
+            pth = os.path.join(args.workdir, "real-%d%s.fmi" % (big, "" if k == 0 else ("-b" if k == 1 else "-%d" % k)))
+            if not os.path.exists(pth):
+                codes = builder.synth_reads(4242 + k, big, args.rlen, 5 * big, args.sub_rate, device=dev, private_frac=0.05 if k else 0.0)
+                builder.build_from_codes(codes, pth + ".tmp")
+                del codes
+                torch.cuda.empty_cache()
+                os.replace(pth + ".tmp", pth)
+                note("4-Gbase sample %d of %d built (%.0f s so far)" % (k + 1, nbig, time.time() - t0))
+            bpaths.append(pth)
         build_s = time.time() - t0
-        with pydsm.Index(pth, device=local) as big_ix:
-            rec = one([big_ix], "1 read set of %d x %d bp (n=%d > 2^32, 64-bit positions), configs[3]'s sample size, pmin=1" % (big, args.rlen, big_ix.n),
-                      pmin=1)
-            rec.update(dtype="u64", index_build_s=build_s)
-            out.append(rec)
+        bixs = [pydsm.Index(pth, device=local) for pth in bpaths]
+        rec = one(bixs[:1], "1 read set of %d x %d bp (n=%d > 2^32, 64-bit positions), configs[3]'s sample size, pmin=1" % (big, args.rlen, bixs[0].n),
+                  pmin=1)
+        rec.update(dtype="u64")
+        out.append(rec)
+        note("one 4-Gbase sample done")
+        if nbig > 1:
+            with pydsm.Miner(bixs, fmin=args.fmin, emax=args.emax, pmin=2, pmax=8, stream=torch.cuda.current_stream().cuda_stream) as m:
+                m.mine_many(prefixes[:1], text=False)  # warm-up: the first prefix only (allocations, pinned buffers)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st = m.mine_many(prefixes, text=False)[1]
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            out.append({"record": "configs[3] one-card share: %d read sets of %d x %d bp (n=%d each) resident on one GPU, d=%d, pmin=2 pmax=8, "
+                                  "64-bit positions" % (nbig, big, args.rlen, bixs[0].n, nbig), "value": st.reported / dt, "unit": "substrings/s",
+                        "ms_per_step": dt * 1e3, "nodes": st.reported, "tuples": st.tuples, "union_nodes": st.union_nodes, "expand_ms": st.expand_ms,
+                        "device_ms": st.device_ms, "splits": st.splits, "max_frontier": st.max_frontier, "dtype": "u64", "index_build_s": build_s,
+                        "index_hbm_bytes": sum(x.device_bytes() for x in bixs)})
+        for x in bixs:
+            x.close()
     except Exception as e:  # noqa: BLE001
-        out.append({"record": "4-Gbase sample", "error": repr(e)})
+        out.append({"record": "4-Gbase samples (configs[3])", "error": repr(e)})
     return out
 
 
@@ -468,7 +515,7 @@ def main():
         esec = tot["expand_ms"] * 1e-3
         ach = kernel_bytes / esec / 1e9 if esec > 0 else 0.0
         ref_equiv = tot["rank_ops"] * ALG_BYTES_PER_RANK / esec / 1e9 if esec > 0 else 0.0
-        traffic = None
+        traffic, tinfo = None, {}
         tj = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 --pmc (see profiles/README)
         if os.path.exists(tj):
             try:
@@ -477,6 +524,7 @@ def main():
                     traffic = tinfo.get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
+        traffic_gbs = (traffic / (tot["expand_ms"] / max(1, tot["launches"]) * 1e-3) / 1e9) if traffic and tot["expand_ms"] > 0 else None
         out = {
             "metric": "enumerated substrings/sec (Emax=2.0)", "value": reported_all / dt, "unit": "substrings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -490,14 +538,21 @@ def main():
                        "exchange": ("none (single process)" if not (world > 1 or forced) else
                                     "dsm_rccl: ncclAllGather from the library's callback, one communicator per lane" if native else
                                     "torch.distributed all_gather_into_tensor (%s) from a Python callback" % dist.get_backend())},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         # `achieved` = bytes the kernel itself counted / HIP-event time of its launches (live, this run).
-                         # `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes of the same command (offline profile,
-                         # profiles/traffic.json; null when this run's configuration differs from the profiled one)
+            # `frac` is the hardware fraction: HBM bytes per launch as the PMC counters saw them (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+            # passes of this command, tools/profiling/r03_final.sh -> profiles/traffic.json; offline, but of this very kernel and
+            # workload) / the HIP-event time of this run's launches / 8 TB/s.  `model_*` = the bytes the kernel itself counted (64 B
+            # per distinct index block of a tile, handles, column entries, planes, records), live in this run.  Without a matching
+            # profile `frac` falls back to the model and says so in `frac_source`.
+            "roofline": {"bound": "hbm", "achieved": traffic_gbs if traffic_gbs is not None else ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (traffic_gbs if traffic_gbs is not None else ach) / HBM_PEAK_GBS,
+                         "frac_source": "pmc traffic (profiles/traffic.json) / live HIP-event time" if traffic_gbs is not None else "kernel byte counters / live HIP-event time",
                          "traffic": traffic, "traffic_source": "profiles/traffic.json (offline rocprofv3 --pmc of the same command)" if traffic else None,
-                         "traffic_gbs": (traffic / (tot["expand_ms"] / max(1, tot["launches"]) * 1e-3) / 1e9) if traffic and tot["expand_ms"] > 0 else None,
+                         "traffic_gbs": traffic_gbs,
+                         "model_gbs": ach, "model_frac": ach / HBM_PEAK_GBS,
                          "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
-                         "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),
+                         "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),                     # HIP events, this run
+                         "rocprof_avg_launch_ms": tinfo.get("rocprof_avg_launch_ms") if traffic else None,  # kernel trace of the profiled run
+                         "rocprof_expand_ms_per_step": tinfo.get("rocprof_expand_ms_per_step") if traffic else None,
                          "bytes_per_launch": kernel_bytes / max(1, tot["launches"]),
                          "bytes_per_node": kernel_bytes / max(1, tot["reported"]),
                          "index_lines_per_node": tot["index_lines"] / max(1, tot["reported"]),

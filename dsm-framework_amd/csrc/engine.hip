@@ -189,6 +189,17 @@ __device__ __forceinline__ u32 bits_below_lane(u64 p) {  // set bits of p below 
     return __builtin_amdgcn_mbcnt_hi((u32)(p >> 32), __builtin_amdgcn_mbcnt_lo((u32)p, 0u));
 }
 
+// Workgroups are dealt round-robin to the eight XCDs, each with its own L2.  The sweeps below write dense arrays in runs that are
+// shorter than a cache line and not aligned to one, so neighbouring workgroups finish each other's lines: block b takes the place
+// xcd_block() in the sweep, which gives every XCD one contiguous range of the level -- neighbouring runs meet in ONE L2 and leave
+// it as whole lines (otherwise two L2s each write back a partial line).
+constexpr u32 NUM_XCD = 8;
+__device__ __forceinline__ u32 xcd_block() {
+    const u32 b = blockIdx.x, G = gridDim.x;
+    const u32 x = b % NUM_XCD, i = b / NUM_XCD, per = G / NUM_XCD, rem = G % NUM_XCD;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // Thread-per-node kernels do little per node; a thread takes NPT nodes a grid-width apart (coalescing is kept) and issues
 // all their loads before using any, so a wave has several lines in flight and the grid is NPT times smaller.
 constexpr int NPT = 4;
@@ -1017,98 +1028,136 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
     if (threadIdx.x == 0) o.h_totals[0] = total;  // (this kernel runs single-tile levels only)
 }
 
-// The same down-sweep for levels of more than one tile, wave by wave with no block-level step: a wave takes 64 parents (and NPT
-// such groups a grid-width apart, all their directory words requested up front); its place inside its 256-parent tile comes
-// from the planes of the tile's earlier waves, the tile's place from the scanned counts.
+// The same down-sweep for levels of more than one tile: one block per tile of 256 parents, one wave per 64.  Everything a wave needs
+// from memory is requested before anything is used -- its planes, the tile's scanned counts, the parents' path words, reader
+// counts and (one sample) column entries -- so a wave waits for one round trip; the waves of the tile then exchange their child
+// counts through LDS (one barrier) and write.
 template <typename P>
 __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o) {
+    __shared__ u32 wcnt[4][4];
     const u32 F = (u32)x.F;
     const int lane = threadIdx.x & 63;
-    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 nw = (F + 63) >> 6;
+    const u32 tile = xcd_block();
+    const u32 wi = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 w = tile * 4 + wi;
+    const bool wave_in = w < nw;   // (the last tile of a level may end before its fourth wave)
+    const u32 wc = wave_in ? w : 0u;
     const u64 lt = (1ull << lane) - 1;
+    const u32 u = w * 64 + lane;
+    const bool in = wave_in && u < F;
+    const u32 uc = in ? u : 0u;
+    // ---- requests ----
+    u64 up[4];
+    u32 base[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        up[c] = o.kplane[(size_t)wc * 4 + c];
+        base[c] = o.cnt4[(size_t)c * o.nbp + tile];
+    }
+    uint2 mypw = make_uint2(0u, 0u);
     uint2* pw = o.pw;
-    if (o.pw_after_slot) pw = reinterpret_cast<uint2*>(reinterpret_cast<u8*>(o.slot) + (((size_t)o.width[0] * 4 + 255) & ~(size_t)255));
+    u32 width = 0;
+    if (o.pw_after_slot) width = o.width[0];
+    if (pw) mypw = o.parent_pw[uc];
+    uint2 sq = make_uint2(0u, 0u);
+    if (o.sinfo) sq = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)uc * 4);
+    u32 myT = 1u;
+    if (!o.single) myT = (u32)o.parent_nT[uc];
+    // one sample: the node's column entry (frequency, flags) for the output predicates, whatever they will decide
+    u64 f1 = 0;
+    u32 l1 = 0;
+    if (o.single && o.filter_on) { f1 = (u64)x_freq<P>(x, 0, uc); l1 = x_pl<P>(x, 0, uc) >> 4; }
+    // ---- the tile's child counts per wave ----
+    if (!wave_in) {
 #pragma unroll
-    for (int it = 0; it < NPT; ++it) {
-        const u32 w = w0 + (u32)it * stride;
-        if (w >= nw) break;
-        const u32 tile = w >> 2, wi = w & 3;
-        const u32 u = w * 64 + lane;
-        u64 up[4];
-        u32 cum[4];
+        for (int c = 0; c < 4; ++c) up[c] = 0;
+    }
+    if (lane < 4) wcnt[wi][lane] = (u32)__popcll(DSM_PICK(up, lane));
+    __syncthreads();
+    if (!wave_in) return;
+    if (o.pw_after_slot) pw = reinterpret_cast<uint2*>(reinterpret_cast<u8*>(o.slot) + (((size_t)width * 4 + 255) & ~(size_t)255));
+    u32 cum[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            up[c] = o.kplane[(size_t)w * 4 + c];
-            u32 before = 0;
-            for (u32 q = 0; q < wi; ++q) before += (u32)__popcll(o.kplane[((size_t)tile * 4 + q) * 4 + c]);
-            cum[c] = o.cnt4[(size_t)c * o.nbp + tile] + before;
-        }
-        u32 nT4[4] = {0, 0, 0, 0};
-        if (o.sinfo) {
-            if (u < F) {
-                const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
-                nT4[0] = q.x & 0xFFFFu; nT4[1] = q.x >> 16; nT4[2] = q.y & 0xFFFFu; nT4[3] = q.y >> 16;
+    for (int c = 0; c < 4; ++c) {
+        u32 before = 0;
+#pragma unroll
+        for (u32 q = 0; q < 3; ++q) before += q < wi ? wcnt[q][c] : 0u;
+        cum[c] = base[c] + before;
+    }
+    u32 nT4[4] = {0, 0, 0, 0};
+    if (o.sinfo) {
+        if (in) { nT4[0] = sq.x & 0xFFFFu; nT4[1] = sq.x >> 16; nT4[2] = sq.y & 0xFFFFu; nT4[3] = sq.y >> 16; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nT4[c] = (u32)((up[c] >> lane) & 1);
+    }
+    if (lane < 4) {
+        o.kcum[(size_t)w * 4 + lane] = DSM_PICK(cum, lane);
+        if (o.kplane_w) o.kplane_w[(size_t)w * 4 + lane] = DSM_PICK(up, lane);
+        if (o.cnt_clear && wi == 0) o.cnt_clear[(size_t)lane * o.nbp + tile] = 0;  // the expand kernels of the next level add into it
+    }
+    u32 pres = 0, lastT = 0, vj[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        vj[c] = cum[c] + (u32)__popcll(up[c] & lt);
+        if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
+    }
+    const u32 nc = __popc(pres);
+    if (!in) myT = 0;
+    const u32 same = o.single ? 1u : ((nc == 1 && lastT == myT) ? 1u : 0u);
+    if (o.filter_on) {
+        bool cand;
+        if (o.single) {
+            // metaserver.cpp:406-419 with one reader: the entropy of a single frequency is 0 up to rounding (the host decides it
+            // exactly), so the thresholds are tested against 0 with the margin
+            const FilterArgs& a = o.fa;
+            cand = in && a.depth >= a.mindepth && 1u >= a.pmin && nc != 1 && !(f1 != 0 && l1 >= 1 && l1 <= 4);  // (one reader never exceeds pmax)
+            if (cand && a.emax > 0) {
+                const u64 sumN = 1ull + f1;
+                const double sl = f1 ? (double)(f1 + 1) * (double)__log2f((float)(f1 + 1)) : 0.0;
+                const double e = (double)__log2f((float)sumN) - sl / (double)sumN;
+                if (e < a.emin - ENT_MARGIN || e > a.emax + ENT_MARGIN) cand = false;
             }
         } else {
+            cand = in && filter_node<P>(o.fa, x, u, myT, nc, same);
+        }
+        const u64 bits = __ballot(cand);
+        u64 pairs = (u64)__popcll(bits);
+        if (!o.single) pairs = wave_sum_u64(cand ? (u64)myT : 0ull);
+        if (lane == 0) { o.candbits[w] = bits; o.wsum[w] = (u64)__popcll(bits) | (pairs << 32); }
+    }
+    if (!in) return;
+    if (!o.single) o.samechild[u] = (u8)same;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) nT4[c] = (u32)((up[c] >> lane) & 1);
+    for (int c = 0; c < 4; ++c) {
+        if (((pres >> c) & 1u) && vj[c] < o.cap) {
+            if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
+            if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
+            if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
         }
-        if (lane < 4) {
-            o.kcum[(size_t)w * 4 + lane] = DSM_PICK(cum, lane);
-            if (o.kplane_w) o.kplane_w[(size_t)w * 4 + lane] = DSM_PICK(up, lane);
-            if (o.cnt_clear && wi == 0) o.cnt_clear[(size_t)lane * o.nbp + tile] = 0;  // the expand kernels of the next level add into it
-        }
-        u32 pres = 0, lastT = 0, vj[4];
+    }
+    if (o.single) {  // one sample: its planes are the union's, its handle table is passed directly
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            vj[c] = cum[c] + (u32)__popcll(up[c] & lt);
-            if (nT4[c]) { pres |= 1u << c; lastT = nT4[c]; }
-        }
-        const u32 nc = __popc(pres);
-        const u32 myT = o.single ? 1u : (u < F ? (u32)o.parent_nT[u] : 0u);
-        const u32 same = o.single ? 1u : ((nc == 1 && lastT == myT) ? 1u : 0u);
-        if (o.filter_on) {
-            const bool cand = u < F && filter_node<P>(o.fa, x, u, myT, nc, same);
-            const u64 bits = __ballot(cand);
-            u64 pairs = (u64)__popcll(bits);
-            if (!o.single) pairs = wave_sum_u64(cand ? (u64)myT : 0ull);
-            if (lane == 0) { o.candbits[w] = bits; o.wsum[w] = (u64)__popcll(bits) | (pairs << 32); }
-        }
-        if (u >= F) continue;
-        if (!o.single) o.samechild[u] = (u8)same;
-        uint2 mypw = make_uint2(0u, 0u);
-        if (pw) mypw = o.parent_pw[u];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (((pres >> c) & 1u) && vj[c] < o.cap) {
-                if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
-                if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
-                if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
-            }
-        }
-        if (o.single) {  // one sample: its planes are the union's, its handle table is passed directly
+        for (int c = 0; c < 4; ++c)
+            if (((pres >> c) & 1u) && vj[c] < o.cap) o.rp0[vj[c]] = (u32)c * o.seg + w * 64u + (u32)__popcll(up[c] & lt);
+        return;
+    }
+    for (u32 sl = 0; sl < o.nlocal && pres && (o.tpos || o.rp_index); ++sl) {
+        u32* rp = o.rp[sl];
+        if (o.tpos) {
+            const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
+            const u32 h = m ? o.tpos[sl][u] : 0u;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (((pres >> c) & 1u) && vj[c] < o.cap) o.rp0[vj[c]] = (u32)c * o.seg + w * 64u + (u32)__popcll(up[c] & lt);
-            continue;
-        }
-        for (u32 sl = 0; sl < o.nlocal && pres && (o.tpos || o.rp_index); ++sl) {
-            u32* rp = o.rp[sl];
-            if (o.tpos) {
-                const u32 m = x_pl<P>(x, o.rank * o.nlocal + sl, u) & 15u;
-                const u32 h = m ? o.tpos[sl][u] : 0u;
+                if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
+        } else {
+            const u64* sp = o.splane[sl] + (size_t)w * 4;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (((pres >> c) & 1u) && vj[c] < o.cap) rp[vj[c]] = ((m >> c) & 1u) ? h + (u32)__popc(m & ((1u << c) - 1u)) : DEAD;
-            } else {
-                const u64* sp = o.splane[sl] + (size_t)w * 4;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
-                    const u64 mine = sp[c];
-                    rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + w * 64u + (u32)__popcll(mine & lt) : DEAD;
-                }
+            for (int c = 0; c < 4; ++c) {
+                if (!((pres >> c) & 1u) || vj[c] >= o.cap) continue;
+                const u64 mine = sp[c];
+                rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + w * 64u + (u32)__popcll(mine & lt) : DEAD;
             }
         }
     }
@@ -1206,7 +1255,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a, Xchg x, const
                                                      const u8* __restrict__ samechild, u64* __restrict__ candbits, u64* __restrict__ wsum) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
     const bool one = a.d == 1;  // a single sample: every node has one reader, a single child always carries it
     u32 t[NPT];
     bool out[NPT];
@@ -1269,7 +1318,7 @@ __global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, c
                                                          u32* __restrict__ ids, u64* __restrict__ freqs) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
     for (u32 w = w0; w < nw; w += stride) {  // few nodes are candidates: most waves only look at their word
         const u64 bits = candbits[w];
         if (!bits) continue;
@@ -1315,28 +1364,41 @@ __global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict_
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
-// A wave takes 64 consecutive nodes (and NPT such groups a grid-width apart): the directory words are wave-uniform.
+// A wave takes 64 consecutive nodes (and NPT such groups a grid-width apart): the directory words are wave-uniform.  The sweeps
+// are latency chains -- directory words, then the gathers they address, then the store -- so a wave issues the loads of one
+// kind for ALL its groups before it uses any (no early exit between them: a group beyond the level reads group 0 and stores
+// nothing, a lane without that child reads entry 0): two round trips per wave instead of two per group.
 // bottom-up: agg[v] = own[v] + sum over children agg_child
 template <typename T, typename OwnT>
 __global__ __launch_bounds__(256) void up_kernel(u32 F, const OwnT* __restrict__ own, Kids kids, const T* __restrict__ child_agg,
                                                  T* __restrict__ agg) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    KidWave kw[NPT];
+    T s[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 w = w0 + (u32)i * stride;
-        if (w >= nw) break;
-        const u32 v = w * 64 + lane;
-        T s = v < F ? (own ? (T)own[v] : (T)1) : (T)0;
-        if (child_agg) {
-            KidWave kw;
-            kid_wave(kids, w, kw);
+        const u32 w = w0 + (u32)i * stride, wc = w < nw ? w : 0u;
+        const u32 v = wc * 64 + lane;
+        s[i] = v < F ? (own ? (T)own[v] : (T)1) : (T)0;
+        if (child_agg) kid_wave(kids, wc, kw[i]);
+    }
+    if (child_agg) {
+        T g[NPT][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((kw.p[c] >> lane) & 1) s += child_agg[kw.c[c] + bits_below_lane(kw.p[c])];
-        }
-        if (v < F) agg[v] = s;
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[i][c] = child_agg[((kw[i].p[c] >> lane) & 1) ? kw[i].c[c] + bits_below_lane(kw[i].p[c]) : 0u];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[i] += ((kw[i].p[c] >> lane) & 1) ? g[i][c] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, v = w * 64 + lane;
+        if (w < nw && v < F) agg[v] = s[i];
     }
 }
 // the same with own[v] = bit v of a word array (null: 0 everywhere): candidates in the subtree
@@ -1345,21 +1407,30 @@ __global__ __launch_bounds__(256) void up_bits_kernel(u32 F, const u64* __restri
                                                       T* __restrict__ agg) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    KidWave kw[NPT];
+    T s[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const u32 w = w0 + (u32)i * stride;
-        if (w >= nw) break;
-        const u32 v = w * 64 + lane;
-        T s = ownbits ? (T)((ownbits[w] >> lane) & 1) : (T)0;
-        if (child_agg) {
-            KidWave kw;
-            kid_wave(kids, w, kw);
+        const u32 w = w0 + (u32)i * stride, wc = w < nw ? w : 0u;
+        s[i] = ownbits ? (T)((ownbits[wc] >> lane) & 1) : (T)0;
+        if (child_agg) kid_wave(kids, wc, kw[i]);
+    }
+    if (child_agg) {
+        T g[NPT][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((kw.p[c] >> lane) & 1) s += child_agg[kw.c[c] + bits_below_lane(kw.p[c])];
-        }
-        if (v < F) agg[v] = s;
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[i][c] = child_agg[((kw[i].p[c] >> lane) & 1) ? kw[i].c[c] + bits_below_lane(kw[i].p[c]) : 0u];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[i] += ((kw[i].p[c] >> lane) & 1) ? g[i][c] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, v = w * 64 + lane;
+        if (w < nw && v < F) agg[v] = s[i];
     }
 }
 // top-down: start[child_k] = start[v] + lead + sum_{j<k} agg[child_j]   (children in A,C,G,T order)
@@ -1368,23 +1439,37 @@ __global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ 
                                                    const T* __restrict__ child_agg, T* __restrict__ child_start) {
     const int lane = threadIdx.x & 63;
     const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
-    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    KidWave kw[NPT];
+    T s[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, wc = w < nw ? w : 0u;
+        const u32 v = wc * 64 + lane;
+        kid_wave(kids, wc, kw[i]);
+        s[i] = start[v < F ? v : 0u] + lead;
+    }
+    // a child's subtree size is needed only when a later sibling exists: most nodes have one child, and their lanes read entry 0
+    T g[NPT][3];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool need = ((kw[i].p[c] >> lane) & 1) && ((((kw[i].p[1] >> lane) & 1) << 1 | ((kw[i].p[2] >> lane) & 1) << 2 | ((kw[i].p[3] >> lane) & 1) << 3) >> (c + 1)) != 0;
+            g[i][c] = child_agg[need ? kw[i].c[c] + bits_below_lane(kw[i].p[c]) : 0u];
+        }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const u32 w = w0 + (u32)i * stride;
-        if (w >= nw) break;
-        const u32 v = w * 64 + lane;
-        KidWave kw;
-        kid_wave(kids, w, kw);
-        T s = (v < F ? start[v] : (T)0) + lead;
-        const u32 m = (u32)((kw.p[0] >> lane) & 1) | ((u32)((kw.p[1] >> lane) & 1) << 1) | ((u32)((kw.p[2] >> lane) & 1) << 2) |
-                      ((u32)((kw.p[3] >> lane) & 1) << 3);
+        if (w >= nw) continue;
+        const u32 m = (u32)((kw[i].p[0] >> lane) & 1) | ((u32)((kw[i].p[1] >> lane) & 1) << 1) | ((u32)((kw[i].p[2] >> lane) & 1) << 2) |
+                      ((u32)((kw[i].p[3] >> lane) & 1) << 3);
+        T acc = s[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if ((m >> c) & 1u) {
-                const u32 ch = kw.c[c] + bits_below_lane(kw.p[c]);
-                child_start[ch] = s;
-                if (m >> (c + 1)) s += child_agg[ch];  // only when a later sibling exists
+                child_start[kw[i].c[c] + bits_below_lane(kw[i].p[c])] = acc;
+                if (c < 3 && (m >> (c + 1))) acc += g[i][c];
             }
         }
     }
@@ -2686,7 +2771,7 @@ class Engine {
             const bool fused_filter = filtered && nbp > 1;
             if (fused_filter) { ao.filter_on = 1; ao.fa = filter_args(F, depth, order_mode); ao.candbits = me.cand_bits; ao.wsum = cand_wsum; }
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
-            else hipLaunchKernelGGL((advance_wave_kernel<P>), grid_for(F), dim3(256), 0, st, x, ao);
+            else hipLaunchKernelGGL((advance_wave_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode, !fused_filter)) return erc;
             }

@@ -91,6 +91,60 @@ def test_whole_pass_invariants(big):
     assert sst.reported == gst.reported and nb > 4 * sst.reported
 
 
+def _host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def test_uncut_one_letter_prefix_equals_oracle(big):
+    """ONE whole one-letter prefix of the configs[1] index, uncut (0.7e9 nodes, 1.7e7 tuples), against the oracle: the sha256 of
+    the reference-format tuple text.  The oracle runs one thread per prefix (like metaenumerate.cpp:268), so it enumerates the
+    1024 six-letter prefixes below "G" in parallel: their outputs, concatenated in prefix order, are the uncut run's text minus
+    its lines for the nodes above depth 6 (post-order keeps every subtree contiguous; with one sample the nodes of an enforced
+    path have one child and are never printed, metaserver.cpp:416-417).  Those few shallow lines are compared with a depth-cut
+    oracle run of "G" (a node's line depends on its children only, which a cut one level below leaves complete)."""
+    import hashlib
+    import itertools
+    import orc
+    pydsm, ix, path, reads = big
+    kw = dict(fmin=10, pmin=1, emax=2.0)
+    with pydsm.Miner([ix], **kw) as m:
+        text, st = m.mine("G")
+    assert st.splits == 0
+    buf = np.frombuffer(text, np.uint8)
+    nl = np.flatnonzero(buf == 10)
+    assert len(nl) == st.tuples and nl[-1] == len(buf) - 1
+    starts = np.concatenate((np.zeros(1, np.int64), nl[:-1] + 1))
+    shallow = np.zeros(len(starts), bool)
+    for k in range(1, 6):  # a space among the first six bytes: a path shorter than six symbols
+        shallow |= buf[np.minimum(starts + k, len(buf) - 1)] == 32
+    deep, top = hashlib.sha256(), []
+    pos = 0
+    for j in np.flatnonzero(shallow):
+        deep.update(memoryview(text)[pos:starts[j]])
+        top.append(bytes(text[starts[j]:nl[j] + 1]))
+        pos = int(nl[j]) + 1
+    deep.update(memoryview(text)[pos:])
+    o = orc.Index(path)
+    threads = min(orc.lib().orc_max_threads(), _host_cores())
+    six = ["G" + "".join(q) for q in itertools.product("ACGT", repeat=5)]
+    want, ost = orc.mine([o], [ix.name], six, threads=threads, **kw)
+    cut, _ = orc.mine([o], [ix.name], ["G"], maxdepth=6, **kw)
+    o.close()
+    assert hashlib.sha256(want).digest() == deep.digest(), "tuple text of the uncut prefix differs from the oracle's"
+    assert len(text) - sum(len(t) for t in top) == len(want)
+    assert top == [ln + b"\n" for ln in cut.split(b"\n") if ln and ln.find(b" ") < 6]
+    # every node of the prefix was counted: the oracle's runs count their six enforced nodes each
+    assert st.reported == ost[0] - 6 * len(six) + sum(4 ** k for k in range(6))
+    print("uncut prefix G: %d nodes, %d tuples, %.2f GB of text, sha256 %s" % (st.reported, st.tuples, len(text) / 1e9, hashlib.sha256(text).hexdigest()[:16]))
+
+
 def test_split_wire_stream_at_full_size(big):
     """Stream mode with buffers far too small for a one-letter prefix of the full-size index: the prefix goes out as slices of
     its sub-prefixes' streams (several levels of splitting) and the bytes equal the unsplit run's -- which, restricted to the
@@ -408,5 +462,41 @@ def test_real_bwt_beyond_2_32():
                 want, ost = orc.mine([o, o2], names, [p], fmin=10, pmin=2, pmax=8, emax=2.0, threads=4)
                 assert got == want, p
                 assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, p
-    o2.close()
-    o.close()
+    # ---- configs[3] at its one-card share: EIGHT 4-Gbase samples resident (8 x 4 GB of index), d = 8, -P 2 --pmax 8, 64-bit
+    # positions (metaserver.cpp:406-419 for the predicates, EnumerateQuery.cpp:151-238 for the enumeration).  DSM_BIGBWT_SAMPLES
+    # shrinks the number of samples (default 8).
+    nsamp = int(os.environ.get("DSM_BIGBWT_SAMPLES", "8"))
+    paths = [path, path2]
+    for k in range(2, nsamp):
+        pk = os.path.join(d, "real-%d-%d.fmi" % (reads, k))
+        if not os.path.exists(pk):
+            t0 = time.time()
+            codes = builder.synth_reads(4242 + k, reads, 100, reads * 5, 0.005, device="cuda", private_frac=0.05)
+            builder.build_from_codes(codes, pk + ".tmp")
+            del codes
+            torch.cuda.empty_cache()
+            os.replace(pk + ".tmp", pk)
+            print("sample %d of %d built in %.1f s" % (k, nsamp, time.time() - t0), flush=True)
+        paths.append(pk)
+    paths = paths[:nsamp]
+    O = [o, o2] + [orc.Index(pk) for pk in paths[2:]]
+    A = [pydsm.Index(pk) for pk in paths]
+    names = [ix.name for ix in A]
+    assert len(set(names)) == nsamp and all(ix.n == n for ix in A)
+    kw = dict(fmin=10, pmin=2, pmax=8, emax=2.0)
+    with pydsm.Miner(A, **kw) as m:
+        for _ in range(3):
+            p = "".join(rng.choice(list("ACGT"), 8))
+            got, st = m.mine(p)
+            want, ost = orc.mine(O[:nsamp], names, [p], threads=8, **kw)
+            assert got == want, p
+            assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, p
+    got, st = pydsm.mine(A, "C", maxdepth=10, **kw)
+    want, ost = orc.mine(O[:nsamp], names, ["C"], maxdepth=10, threads=8, **kw)
+    assert got == want and (st.reported, st.union_nodes, st.tuples, st.pairs) == (ost[0], ost[3], ost[4], ost[5])
+    print("configs[3] share: %d samples of n = %d, prefix C cut at depth 10: %d nodes, %d tuples, splits %d, max_frontier %d" % (
+        nsamp, n, st.reported, st.tuples, st.splits, st.max_frontier), flush=True)
+    for ix in A:
+        ix.close()
+    for ox in O:
+        ox.close()
