@@ -213,7 +213,10 @@ struct ExpandArgs {
     u32 nbp;          // tiles of the level = stride of cnt4
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
-    u32 symbol_phase; // bit 0: node is handled by nextSymbol (size-1 nodes take followOneBranch); bit 1: the children count as reported
+    u32 symbol_phase; // bit 0: node is handled by nextSymbol (size-1 nodes take followOneBranch); bit 1: the children count as reported;
+                      // bit 2 (one sample): the level's nodes are tested for output here -- everything in metaserver.cpp:406-419 that does
+                      // not depend on the node (depth, pmin, the entropy thresholds against the 0 a single frequency gives) holds;
+                      // bit 3 (one sample): a tile's planes form a 64-byte line {plane[4], candidate bits, candidates | pairs << 32, -, -}
     u32 w16;          // this level's column: 0 = frequencies as P plus a flag byte; 1 = 16-bit frequencies plus a flag byte (every
                       // frequency of the level is below 65535); 2 = ONE 16-bit word per node, frequency in bits 0-8 and the flags
                       // in bits 9-15 (every frequency below 512: all but the top levels of a prefix)
@@ -492,7 +495,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     }
     if (lane < 4) {
         const u64 b = DSM_PICK(bal, lane);
-        splane[(size_t)t * 4 + lane] = b;
+        if (!(a.symbol_phase & 8u)) splane[(size_t)t * 4 + lane] = b;
         const u32 nb = (u32)__popcll(b);
         if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
     }
@@ -503,6 +506,16 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
 #pragma unroll
             for (int e = 2; e < 4; ++e)
                 if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * cap + nd.r] == sp && rec[(size_t)(3 + 2 * e) * cap + nd.r] == ep) matches = true;
+        }
+    }
+    const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
+    if (a.symbol_phase & 8u) {  // one sample: planes and the level's candidates in one line per tile (the advance sweep reads it)
+        // metaserver.cpp:406-419 for a node with one reader: not a single child (416-417), no single left char (383-387, 418)
+        const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u));
+        if (lane < 6) {
+            const u64 nc = (u64)__popcll(cb);
+            const u64 word = lane < 4 ? DSM_PICK(bal, lane) : (lane == 4 ? cb : (nc | (nc << 32)));
+            splane[(size_t)t * 8 + lane] = word;
         }
     }
     // ---- child records.  A lane's work is the list of its (child, left-extension interval) pairs, child-major: most lanes have
@@ -569,7 +582,6 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             }
         }
     }
-    const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
     if (i < a.F) {
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16 == 2) {
@@ -861,6 +873,8 @@ struct AdvanceOut {
     const u32* width;
     u32 pw_after_slot;
     u32 plevel;       // level of the parents
+    u32 kshift;       // log2 of the words per wave in kplane: 2, or 3 when the expand kernel of a single sample wrote whole lines
+    u32 cand_copy;    // ... whose words 4 and 5 are the wave's candidate bits and counts: copied to candbits / wsum here
     u16* nT;          // per new node
     u8* samechild;    // per parent: single child that carries every reader (metaserver.cpp:416-417)
     const u16* parent_nT;
@@ -944,7 +958,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
     } else {
         const bool inside = wv * 64 < F;  // the expand kernel writes planes for the waves that hold nodes only
 #pragma unroll
-        for (int c = 0; c < 4; ++c) up[c] = inside ? o.kplane[wv * 4 + c] : 0ull;
+        for (int c = 0; c < 4; ++c) up[c] = inside ? o.kplane[(wv << o.kshift) + c] : 0ull;
         if (o.sinfo) {
             if (u < F) {
                 const uint2 q = *reinterpret_cast<const uint2*>(o.sinfo + (size_t)u * 4);
@@ -1052,7 +1066,7 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
     u32 base[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        up[c] = o.kplane[(size_t)wc * 4 + c];
+        up[c] = o.kplane[((size_t)wc << o.kshift) + c];
         base[c] = o.cnt4[(size_t)c * o.nbp + tile];
     }
     uint2 mypw = make_uint2(0u, 0u);
@@ -1065,6 +1079,8 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
     u32 myT = 1u;
     if (!o.single) myT = (u32)o.parent_nT[uc];
     // one sample: the node's column entry (frequency, flags) for the output predicates, whatever they will decide
+    u64 candw = 0;  // (lanes 4 and 5: the wave's candidate bits and counts as the expand kernel left them)
+    if (o.cand_copy && (lane == 4 || lane == 5)) candw = o.kplane[((size_t)wc << 3) + lane];
     u64 f1 = 0;
     u32 l1 = 0;
     if (o.single && o.filter_on) { f1 = (u64)x_freq<P>(x, 0, uc); l1 = x_pl<P>(x, 0, uc) >> 4; }
@@ -1096,6 +1112,10 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
         o.kcum[(size_t)w * 4 + lane] = DSM_PICK(cum, lane);
         if (o.kplane_w) o.kplane_w[(size_t)w * 4 + lane] = DSM_PICK(up, lane);
         if (o.cnt_clear && wi == 0) o.cnt_clear[(size_t)lane * o.nbp + tile] = 0;  // the expand kernels of the next level add into it
+    }
+    if (o.cand_copy) {
+        if (lane == 4) o.candbits[w] = candw;
+        if (lane == 5) o.wsum[w] = candw;
     }
     u32 pres = 0, lastT = 0, vj[4];
 #pragma unroll
@@ -2338,7 +2358,7 @@ class Engine {
             if (!trie_mode) {
                 if (int rc = dalloc(a, rec_elems<P>(Rcap))) return rc;
                 if (int rc = dalloc(b, rec_elems<P>(Rcap))) return rc;
-                if (int rc = dalloc(pln, nwave * 4)) return rc;
+                if (int rc = dalloc(pln, nwave * (d == 1 ? 8 : 4))) return rc;  // (one sample: whole lines per tile, see ExpandArgs::symbol_phase)
             } else {
                 if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
             }
@@ -2592,6 +2612,12 @@ class Engine {
             }
             // `reported` counts a node once however a prefix was split: a run counts the depths it is responsible for
             if (count && depth + 1 >= emit_lo && depth + 1 <= emit_hi) ea.symbol_phase |= 2u;
+            if (d == 1 && !trie_mode) {  // one sample: the output predicates of this level's nodes are evaluated by its LF-step kernel
+                ea.symbol_phase |= 8u;
+                const bool emit_level = !stream_mode && emit && depth >= 1 && depth >= emit_lo && depth <= emit_hi;
+                const bool ent_ok = !(prm.emax > 0 && (0.0 < prm.emin - ENT_MARGIN || 0.0 > prm.emax + ENT_MARGIN));
+                if (emit_level && depth >= prm.mindepth && prm.pmin <= 1 && ent_ok) ea.symbol_phase |= 4u;
+            }
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
@@ -2751,7 +2777,7 @@ class Engine {
             ao.tpos = trie_mode ? d_tpos_tab : nullptr;
             ao.splane = d_splane_tab;
             ao.rp_index = self_mode ? 0u : 1u;
-            ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp;
+            ao.kcum = me.kcum; ao.cnt4 = cnt4; ao.nbp = nbp; ao.kshift = 2;
             ao.width = d_totals;  // (levels of several tiles: the scan's grand total)
             const bool merged = d > 1 || trie_mode;  // the union of several columns (a parsed stream is treated alike)
             if (merged && nbp == 1) {  // a single tile evaluates the columns itself
@@ -2761,6 +2787,7 @@ class Engine {
                 ao.kplane = me.kplane; ao.sinfo = sinfo;
             } else {                   // one sample: the union trie is its trie, the expand kernel wrote planes and tile counts
                 ao.kplane = splane[0]; ao.kplane_w = me.kplane; ao.single = 1;
+                ao.kshift = 3;
             }
             if (nbp > 1) {
                 exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
@@ -2769,7 +2796,11 @@ class Engine {
             // ---- the output predicates for the nodes of THIS level (their children are known now) ride in the wave sweep; the scan of
             // the candidate counts is queued ahead of the wait ----
             const bool fused_filter = filtered && nbp > 1;
-            if (fused_filter) { ao.filter_on = 1; ao.fa = filter_args(F, depth, order_mode); ao.candbits = me.cand_bits; ao.wsum = cand_wsum; }
+            if (fused_filter) {
+                ao.fa = filter_args(F, depth, order_mode); ao.candbits = me.cand_bits; ao.wsum = cand_wsum;
+                if (ao.single) ao.cand_copy = 1;  // (the level's LF-step kernel decided: the sweep only moves the words into place)
+                else ao.filter_on = 1;
+            }
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
             else hipLaunchKernelGGL((advance_wave_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             if (filtered) {

@@ -13,6 +13,7 @@ path itself never touches torch kernels.  Gate (tests/test_builder.py): the BWT 
 from the reference builder's .fmi of the same FASTA, and the unmodified reference metaenumerate produces
 identical streams from our file.
 """
+import os
 import struct
 
 import numpy as np
@@ -303,8 +304,42 @@ def _wt_node(seq, code_lut, level, out):
     _wt_node(right, code_lut, level + 1, out)
 
 
-def write_fmi(bwt, path, number_of_texts, max_text_length):
-    """FMIndex::save (FMIndex.cpp:155-217), version 17, no samples / names / text storage."""
+def write_fmi_hip(bwt, path, number_of_texts, max_text_length):
+    """The same file from libdsmhip's dsm_fmi_write (csrc/fmiwrite.hip: wavelet-tree bit vectors and rank directories on the GPU)."""
+    import ctypes as C
+    from . import lib, _check
+    L = lib()
+    L.dsm_fmi_write.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p]
+    L.dsm_fmi_write.restype = C.c_int
+    bwt = bwt.contiguous()
+    torch.cuda.synchronize(bwt.device)
+    _check(L.dsm_fmi_write(bwt.data_ptr(), bwt.numel(), int(number_of_texts), int(max_text_length), SAMPLERATE, bwt.device.index or 0,
+                           os.fsencode(path)))
+    return {"n": int(bwt.numel())}
+
+
+def build_fasta_hip(fasta_path, out_path, device=0):
+    """FASTA file -> .fmi entirely inside the library (dsm_build_fasta; what host/builder_hip calls)."""
+    import ctypes as C
+    from . import lib, _check
+
+    class Info(C.Structure):
+        _fields_ = [("n", C.c_uint64), ("number_of_texts", C.c_uint64), ("max_text_length", C.c_uint64)]
+    L = lib()
+    L.dsm_build_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(Info)]
+    L.dsm_build_fasta.restype = C.c_int
+    info = Info()
+    _check(L.dsm_build_fasta(os.fsencode(fasta_path), os.fsencode(out_path), SAMPLERATE, device, C.byref(info)))
+    return {"n": info.n, "number_of_texts": info.number_of_texts, "max_text_length": info.max_text_length}
+
+
+def write_fmi(bwt, path, number_of_texts, max_text_length, hip=None):
+    """FMIndex::save (FMIndex.cpp:155-217), version 17, no samples / names / text storage.
+    hip: write through the library (default: whenever the BWT lives on the GPU); False = the torch tooling below (also CPU)."""
+    if hip is None:
+        hip = bwt.is_cuda
+    if hip:
+        return write_fmi_hip(bwt, path, number_of_texts, max_text_length)
     n = int(bwt.numel())
     counts = torch.bincount(bwt.long(), minlength=256).cpu().numpy().astype(np.uint64)
     C = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype("<u8")     # FMIndex::makewavelet, FMIndex.cpp:395-410

@@ -263,6 +263,23 @@ void dsm_free(void* p);
  * ---------------------------------------------------------------------------------------------- */
 int dsm_bwt_build(const uint8_t* d_text, uint64_t n, uint8_t* d_bwt, int device, void* stream);
 
+/* The rest of the reference `builder` (builder.cpp:329-472) behind the same boundary.
+ * dsm_fmi_write: a BWT on the device -> <path> as .fmi version 17: the Huffman code table with the tie order of the reference's
+ *   std::priority_queue (HuffWT.cpp:133-171), the pre-order wavelet tree with one BitRank per internal node (HuffWT.cpp:5-86:
+ *   bit vector, Rs per 256 bits, Rb per word, BitRank.cpp:134-187) and FMIndex::save's container (FMIndex.cpp:155-217; no
+ *   samples, names or text storage -- enumeration reads none).  Byte-identical to the reference builder's file of the same reads.
+ * dsm_build_fasta: the whole tool: FASTA records (builder.cpp:203-262), per read upper-case / N-normalised (:60-104),
+ *   text = reverse(read + '-' + revcomp(read)) + '\0' (:183-201), BWT by dsm_bwt_build, file by dsm_fmi_write.
+ *   out_path is the file itself (the CLI appends ".fmi" like TextCollection::save). */
+typedef struct dsm_build_info {
+    uint64_t n;                /* BWT symbols */
+    uint64_t number_of_texts;  /* reads */
+    uint64_t max_text_length;  /* longest text with its terminator */
+} dsm_build_info;
+int dsm_fmi_write(const uint8_t* d_bwt, uint64_t n, uint32_t number_of_texts, uint64_t max_text_length, uint32_t samplerate, int device,
+                  const char* path);
+int dsm_build_fasta(const char* fasta_path, const char* out_path, uint32_t samplerate, int device, dsm_build_info* info);
+
 /* ------------------------------------------------------------------------------------------------
  * Distance matrices of the tuple stream: the accumulation of wrapper-distance-matrix/smtxt2entropy.c
  * on the GPU.

@@ -141,3 +141,45 @@ def test_hip_bwt_equals_prefix_doubling_on_a_read_set(builder):
         assert torch.equal(builder.bwt_collection(sym, hip=True), want)
     finally:
         del os.environ["DSM_BWT_BATCH"]
+
+
+# ---- the library's builder (csrc/fmiwrite.hip, host/builder_hip): the reference `builder` as a C++ drop-in -------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname,name", [("toy3", "toy-1"), ("toyN", "toyN"), ("five", "five-3")])
+def test_builder_hip_cli_writes_the_reference_builders_file(golden, tmp_path, setname, name):
+    """host/builder_hip <fasta> (FASTA parse, normalisation, BWT, Huffman shape, bit vectors, rank directories, container -- all
+    behind the C ABI) writes byte for byte the file the reference builder wrote for the same FASTA (builder.cpp:329-472)."""
+    exe = os.path.join(ROOT, "dsm-framework_amd", "host", "builder_hip")
+    fa = tmp_path / (name + ".fasta")
+    fa.write_text(golden.fasta(setname, name))
+    r = subprocess.run([exe, "-v", str(fa)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert open(str(fa) + ".fmi", "rb").read() == open(golden.fmi(setname, name), "rb").read()
+    # an output name: <output>.fmi (builder.cpp:391-393, 425-426)
+    r = subprocess.run([exe, str(fa), str(tmp_path / "other")], capture_output=True)
+    assert r.returncode == 0 and open(str(tmp_path / "other.fmi"), "rb").read() == open(golden.fmi(setname, name), "rb").read()
+    r = subprocess.run([exe, str(tmp_path / "missing.fasta")], capture_output=True)
+    assert r.returncode == 1 and b"unable to read input file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_library_writer_equals_torch_writer(builder, tmp_path):
+    """dsm_fmi_write against the torch tooling on awkward collections: variable lengths, N and lower case, a read set whose
+    bit vectors are not multiples of 64 / 256 bits, and a larger seeded set."""
+    fasta = ">a\nACGTNNAC\n>b\nA\n>c\nacgtRYacgtacgtacgtt\n>d\nTTTTTTTTTTTT\n>e\nTTTTTTTTTTTT\n"
+    fa = tmp_path / "v.fasta"
+    fa.write_text(fasta)
+    builder.build_fasta_hip(str(fa), str(tmp_path / "v.lib.fmi"))
+    builder.build_from_fasta(fasta, str(tmp_path / "v.torch.fmi"))
+    assert open(str(tmp_path / "v.lib.fmi"), "rb").read() == open(str(tmp_path / "v.torch.fmi"), "rb").read()
+    codes = builder.synth_reads(seed=11, nreads=20011, rlen=37, genome_len=50000, sub_rate=0.01, device="cuda")
+    sym = builder.texts_from_codes(codes)
+    bwt = builder.bwt_collection(sym, hip=True)
+    builder.write_fmi(bwt, str(tmp_path / "s.lib.fmi"), 20011, 76, hip=True)
+    builder.write_fmi(bwt.cpu(), str(tmp_path / "s.torch.fmi"), 20011, 76, hip=False)
+    assert open(str(tmp_path / "s.lib.fmi"), "rb").read() == open(str(tmp_path / "s.torch.fmi"), "rb").read()
+    # a file without a trailing newline: the reference reads rows with getline(...).good() and drops the unterminated one
+    fb = tmp_path / "w.fasta"
+    fb.write_text(">a\nACGT\n>b\nGGGTTT")
+    info = builder.build_fasta_hip(str(fb), str(tmp_path / "w.fmi"))
+    assert info["number_of_texts"] == 1 and info["n"] == 10
