@@ -504,6 +504,26 @@ def main():
         reported_all = float(tsum[1])
     else:
         reported_all = float(tot["reported"])
+    # text formatting is outside the timed region (the sink receives binary batches): one more pass, untimed as a whole, in which
+    # only the calls of dsm_format_batch (metaserver.cpp:472-484's printf loop, multi-threaded in the library) are timed
+    format_ms, format_bytes = None, 0
+    if rank == 0 and world == 1 and not args.stream_mode and not forced:
+        import ctypes as C
+        acc = {"s": 0.0, "bytes": 0}
+
+        def fmt(b):
+            t = C.c_void_p()
+            n = C.c_size_t(0)
+            t1 = time.perf_counter()
+            rc = pydsm.lib().dsm_format_batch(C.byref(b), C.byref(t), C.byref(n))
+            acc["s"] += time.perf_counter() - t1
+            if rc == 0:
+                acc["bytes"] += n.value
+                pydsm.lib().dsm_free(t)
+
+        with torch.cuda.stream(lanes[0]["stream"]):
+            lanes[0]["miner"].mine_many(lanes[0]["prefixes"], text=False, on_batch=fmt)
+        format_ms, format_bytes = acc["s"] * 1e3, acc["bytes"]
     for ln in lanes:
         ln["miner"].close()
 
@@ -569,6 +589,7 @@ def main():
                        "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
                        "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
                        "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,
+                       "format_ms_per_step": format_ms, "format_text_bytes_per_step": format_bytes,
                        "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps)},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)

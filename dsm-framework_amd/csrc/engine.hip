@@ -1189,45 +1189,74 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
 // REVERSE insertion order; the insertion sequence into children[c] follows readChildren() round by
 // round (metaserver.cpp:159-189, 322-339).  Orders are nibble-packed, first iterated id in bits 0-3.
 // ---------------------------------------------------------------------------------------------
+// Most nodes have ONE child in the union trie: all readers that go on enter it in the parent's order, so its set iterates in the
+// reverse of that.  Those nodes are done in the first phase; the nodes with several children -- a few per wave, but nearly every
+// wave has one -- are queued in LDS and replayed round by round afterwards by as many lanes as there are such nodes, instead of
+// every wave running the replay for its few.
 template <typename P>
-__global__ void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, Kids kids,
-                             u64* __restrict__ order_next) {
-    u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= F) return;
-    const u32 cnt = nT[u];
-    const u64 ord = order[u];
-    u64 mbyid = 0;  // 4 presence bits per reader id (ids < 16)
-    for (u32 k = 0; k < cnt; ++k) {
-        u32 r = (u32)((ord >> (4 * k)) & 15);
-        u64 m = x_pl<P>(x, r, u) & 15u;  // which children this reader continues into
-        mbyid |= m << (4 * r);
-    }
-    u64 ins[4] = {0, 0, 0, 0};
-    u32 icnt[4] = {0, 0, 0, 0};
-    // round 1: every reader of the parent reads its first child
-    for (u32 k = 0; k < cnt; ++k) {
-        u32 r = (u32)((ord >> (4 * k)) & 15);
-        u32 m = (u32)((mbyid >> (4 * r)) & 15);
-        if (m) {
-            int f = __ffs(m) - 1;
-            ins[f] |= (u64)r << (4 * icnt[f]);
-            ++icnt[f];
+__global__ __launch_bounds__(256) void order_kernel(u32 F, Xchg x, const u16* __restrict__ nT, const u64* __restrict__ order, Kids kids,
+                                                    u64* __restrict__ order_next) {
+    __shared__ u32 qn;
+    __shared__ u32 qu[256];
+    __shared__ u64 qm[256], qo[256];
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < F) {
+        const u32 cnt = nT[u];
+        const u64 ord = order[u];
+        u64 mbyid = 0;  // 4 presence bits per reader id (ids < 16)
+        u32 um = 0;     // children of the node in the union
+        for (u32 k = 0; k < cnt; ++k) {
+            const u32 r = (u32)((ord >> (4 * k)) & 15);
+            const u32 m = x_pl<P>(x, r, u) & 15u;  // which children this reader continues into
+            mbyid |= (u64)m << (4 * r);
+            um |= m;
+        }
+        if (um && !(um & (um - 1))) {  // one child: the readers that enter it, last one first
+            u64 rev = 0;
+            for (u32 k = 0; k < cnt; ++k) {
+                const u32 r = (u32)((ord >> (4 * k)) & 15);
+                if ((mbyid >> (4 * r)) & 15) rev = (rev << 4) | r;
+            }
+            order_next[kid_index(kids, u, (u32)(__ffs((int)um) - 1))] = rev;
+        } else if (um) {
+            const u32 q = atomicAdd(&qn, 1u);
+            qu[q] = u; qm[q] = mbyid; qo[q] = ord;
         }
     }
-    for (int i = 0; i < 4; ++i) {
-        if (!icnt[i]) continue;
-        // iteration order of children[i] = reverse insertion order
-        u64 rev = 0;
-        for (u32 k = 0; k < icnt[i]; ++k) rev |= ((ins[i] >> (4 * k)) & 15) << (4 * (icnt[i] - 1 - k));
-        order_next[kid_index(kids, u, (u32)i)] = rev;
-        // next round: the readers of this child (in its iteration order) read their next child
-        for (u32 k = 0; k < icnt[i]; ++k) {
-            u32 r = (u32)((rev >> (4 * k)) & 15);
-            u32 m = (u32)((mbyid >> (4 * r)) & 15) & ~((2u << i) - 1);
+    __syncthreads();
+    for (u32 q = threadIdx.x; q < qn; q += blockDim.x) {
+        const u32 v = qu[q];
+        const u64 mbyid = qm[q], ord = qo[q];
+        const u32 cnt = nT[v];
+        u64 ins[4] = {0, 0, 0, 0};
+        u32 icnt[4] = {0, 0, 0, 0};
+        // round 1: every reader of the parent reads its first child
+        for (u32 k = 0; k < cnt; ++k) {
+            u32 r = (u32)((ord >> (4 * k)) & 15);
+            u32 m = (u32)((mbyid >> (4 * r)) & 15);
             if (m) {
-                int g = __ffs(m) - 1;
-                ins[g] |= (u64)r << (4 * icnt[g]);
-                ++icnt[g];
+                int f = __ffs(m) - 1;
+                ins[f] |= (u64)r << (4 * icnt[f]);
+                ++icnt[f];
+            }
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (!icnt[i]) continue;
+            // iteration order of children[i] = reverse insertion order
+            u64 rev = 0;
+            for (u32 k = 0; k < icnt[i]; ++k) rev |= ((ins[i] >> (4 * k)) & 15) << (4 * (icnt[i] - 1 - k));
+            order_next[kid_index(kids, v, (u32)i)] = rev;
+            // next round: the readers of this child (in its iteration order) read their next child
+            for (u32 k = 0; k < icnt[i]; ++k) {
+                u32 r = (u32)((rev >> (4 * k)) & 15);
+                u32 m = (u32)((mbyid >> (4 * r)) & 15) & ~((2u << i) - 1);
+                if (m) {
+                    int g = __ffs(m) - 1;
+                    ins[g] |= (u64)r << (4 * icnt[g]);
+                    ++icnt[g];
+                }
             }
         }
     }
@@ -1339,10 +1368,20 @@ __global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, c
     const int lane = threadIdx.x & 63;
     const u32 nw = (a.F + 63) >> 6, stride = gridDim.x * 4;
     const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
-    for (u32 w = w0; w < nw; w += stride) {  // few nodes are candidates: most waves only look at their word
-        const u64 bits = candbits[w];
+    // (few nodes are candidates: most waves only look at their words.  The words of all of a wave's groups are requested first.)
+    u64 bitsv[NPT], basev[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, wc = w < nw ? w : 0u;
+        bitsv[i] = w < nw ? candbits[wc] : 0ull;
+        basev[i] = wscan[wc];
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride;
+        const u64 bits = bitsv[i];
         if (!bits) continue;
-        const u64 base = wscan[w];
+        const u64 base = basev[i];
         const bool mine = (bits >> lane) & 1;
         const u32 v = w * 64 + lane;
         const u32 cnt = mine ? (a.d > 1 ? (u32)nT[v] : 1u) : 0u;  // pairs of this lane's candidate = samples that hold the node
@@ -2319,7 +2358,10 @@ class Engine {
                    + (u64)nlocal * (sizeof(P) + 1)                             // send
                    + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
-        u64 fc = budget / 3 / perF;
+        // Share of the frontier buffers: a third of the budget for one sample (the retained levels need the rest); with several
+        // samples the per-slot cost is dominated by the samples' record buffers while a prefix retains about as much as with one
+        // sample, so two thirds go to the frontier -- eight 1-Gbase samples then take a one-letter prefix without splitting it.
+        u64 fc = budget * (nlocal > 1 ? 2 : 1) / 3 / perF;
         if (fc > (1u << 28) - TILE) fc = (1u << 28) - TILE;
         if (fc < 512) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         if (fc > fbound) fc = fbound < 1024 ? 1024 : fbound;
