@@ -540,7 +540,8 @@ def main():
         if os.path.exists(tj):
             try:
                 tinfo = json.load(open(tj))
-                if tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == plen and tinfo.get("gpus") == args.gpus:
+                if (tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == plen and tinfo.get("gpus") == args.gpus and args.nlocal == 1
+                        and not args.wide and not args.stream_mode):
                     traffic = tinfo.get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None

@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) =
     expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
 }
 
+constexpr u32 BC_OK = 0x4f4b4f4bu, BC_CAPACITY = 0x46554c4cu;  // first word of the owner's broadcast: go on / split this prefix
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
 // Several engines of one process (prefix lanes on their own streams) share the device.  Their expand launches are chained:
 // each waits for the previously issued expand of the process on that device, so two LF-step kernels never run side by
@@ -918,6 +919,7 @@ struct PublishArgs {
     u32* next;            // device copy of the new level's width and frequency class for an expand launch queued ahead (may be null)
     uint4* packet;        // pinned, 16-byte aligned
     u32 seq;
+    uint4* bc_header;     // owner mode: the same packet at the head of the broadcast message (device), may be null
 };
 __global__ void publish_kernel(PublishArgs a) {
     __shared__ u32 wide;  // bit 0: some child frequency of the level is 65535 or more, bit 1: 512 or more
@@ -933,7 +935,9 @@ __global__ void publish_kernel(PublishArgs a) {
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         if (a.next) { a.next[0] = tot; a.next[1] = wide; }
-        *a.packet = make_uint4(a.seq, tot | ((wide & 1u) << 31) | ((wide >> 1) << 30), (u32)cand, (u32)(cand >> 32));  // one global_store_dwordx4
+        const uint4 pk = make_uint4(a.seq, tot | ((wide & 1u) << 31) | ((wide >> 1) << 30), (u32)cand, (u32)(cand >> 32));
+        if (a.bc_header) *a.bc_header = make_uint4(BC_OK, pk.y, 0u, 0u);  // what the clients need: width and frequency class of the new level
+        *a.packet = pk;  // one global_store_dwordx4
     }
 }
 
@@ -1180,6 +1184,46 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
                 rp[vj[c]] = ((mine >> lane) & 1) ? (u32)c * o.seg + w * 64u + (u32)__popcll(mine & lt) : DEAD;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Owner mode, on the ranks that do NOT merge the prefix: the owner's broadcast carries the union's child planes of the level
+// (4 x 64 bits per 64 parents); from them a client only needs the next level's links (4 * parent + symbol), from which its
+// LF-step kernel derives the handles of its own records (expand_tile, SELF).  Tile counts, one scan, links.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__ kplane, u32 nw, u32* __restrict__ cnt4, u32 nbp) {
+    const u32 tile = blockIdx.x * 64 + (threadIdx.x >> 2), c = threadIdx.x & 3;  // one thread per (tile, symbol)
+    if (tile >= nbp) return;
+    u32 s = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) { const u32 w = tile * 4 + q; if (w < nw) s += (u32)__popcll(kplane[(size_t)w * 4 + c]); }
+    cnt4[(size_t)c * nbp + tile] = s;
+}
+__global__ __launch_bounds__(256) void lite_slot_kernel(const u64* __restrict__ kplane, u32 F, const u32* __restrict__ cnt4, u32 nbp, u32 single_tile,
+                                                        u32* __restrict__ slot, u32 cap) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6;
+    const u32 tile = xcd_block();
+    const u32 wi = threadIdx.x >> 6, w = tile * 4 + wi;
+    if (w >= nw) return;
+    const u32 u = w * 64 + lane;
+    u32 base = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32 before = 0, all = 0;
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+            const u32 wq = tile * 4 + q;
+            const u32 t = wq < nw ? (u32)__popcll(kplane[(size_t)wq * 4 + c]) : 0u;
+            before += q < wi ? t : 0u;
+            all += t;
+        }
+        const u64 up = kplane[(size_t)w * 4 + c];
+        const u32 first = (single_tile ? base : cnt4[(size_t)c * nbp + tile]) + before;
+        base += all;
+        const u32 vj = first + (u32)__popcll(up & ((1ull << lane) - 1));
+        if (u < F && ((up >> lane) & 1) && vj < cap) slot[vj] = 4u * u + (u32)c;
     }
 }
 
@@ -2223,6 +2267,11 @@ class Engine {
     // frontier buffers
     u32 Fcap = 0;
     bool multi = false;       // the level exchange goes through the host's all-gather (world > 1, or forced for rehearsals)
+    bool owner_mode = false;  // ... or: columns go to the prefix's owner only, which sends back the union's child planes (dsm_gather_fn)
+    bool is_owner = true;     // this rank merges the prefix (always, unless owner_mode)
+    int owner = 0;
+    u8* bc_buf = nullptr;     // owner mode: the broadcast message, 16-byte header + 32 bytes per 64 parents
+    u32* lite_slot[2] = {nullptr, nullptr};  // owner mode, clients: links of the levels (ping-pong)
     u32 pub_seq = 0;          // sequence number of the last publish kernel
     u32 Seg = 0;              // handles per symbol segment of a record buffer: Fcap rounded up to whole tiles
     u32 Rcap = 0;             // handles of a record buffer = 4 * Seg
@@ -2327,6 +2376,14 @@ class Engine {
         // rehearsal aid: a single rank that still drives the whole exchange path (send buffer, callback, status words)
         multi = world > 1 || (p.allgather && getenv("DSM_FORCE_EXCHANGE"));
         if (world > 1 && !p.allgather) return fail(DSM_E_INVAL, "world_size > 1 needs an allgather callback");
+        owner_mode = multi && p.owner_mode != 0;
+        if (owner_mode) {
+            if (!p.gather || !p.bcast) return fail(DSM_E_INVAL, "owner_mode needs the gather and bcast callbacks");
+            if ((int)p.owner_rank >= world) return fail(DSM_E_INVAL, "owner_rank >= world_size");
+            if (stream || trie_mode) return fail(DSM_E_INVAL, "owner_mode is for mining indexes");
+            owner = (int)p.owner_rank;
+            is_owner = rank == owner;
+        }
         if (rank >= world) return fail(DSM_E_INVAL, "rank >= world_size");
         if (n > MAX_LOCAL) return fail(DSM_E_INVAL, "at most 273 local samples per process");
         d = (u32)(world * nlocal);
@@ -2341,6 +2398,7 @@ class Engine {
         if (const char* e = getenv("DSM_SPEC")) spec_mode = spec_mode && atoi(e) != 0;
         if (spec_mode) { if (int rc = dalloc(d_dyn, (size_t)4)) return rc; }
         self_mode = d > 1 && !trie_mode && batch_mode;
+        if (owner_mode && !self_mode) return fail(DSM_E_INVAL, "owner_mode needs handles derived in the LF-step kernel (several samples, DSM_BATCH not 0)");
         // A frontier level holds disjoint suffix intervals, so it is never wider than the indexed text; the
         // union over d samples is bounded by the sum.  Size the default budget from that, not from the card.
         const u64 fbound = (world > 1 ? (u64)d * nmax : nsum) + 16;
@@ -2361,7 +2419,8 @@ class Engine {
         // Share of the frontier buffers: a third of the budget for one sample (the retained levels need the rest); with several
         // samples the per-slot cost is dominated by the samples' record buffers while a prefix retains about as much as with one
         // sample, so two thirds go to the frontier -- eight 1-Gbase samples then take a one-letter prefix without splitting it.
-        u64 fc = budget * (nlocal > 1 ? 2 : 1) / 3 / perF;
+        // (the default sizing only: an explicit budget is split as before)
+        u64 fc = budget * (nlocal > 1 && !p.arena_bytes ? 2 : 1) / 3 / perF;
         if (fc > (1u << 28) - TILE) fc = (1u << 28) - TILE;
         if (fc < 512) return fail(DSM_E_NOMEM, "not enough device memory for the frontier buffers");
         if (fc > fbound) fc = fbound < 1024 ? 1024 : fbound;
@@ -2420,6 +2479,10 @@ class Engine {
         if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
         if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
+        if (owner_mode) {
+            if (int rc = dalloc(bc_buf, 16 + 32 * nwave + 64)) return rc;
+            for (int k = 0; k < 2; ++k) if (int rc = dalloc(lite_slot[k], (size_t)Fcap + 64)) return rc;
+        }
         if (d == 1 && !trie_mode) {
             if (int rc = dalloc(cntraw, 4 * ntile + 8)) return rc;
             DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
@@ -2764,10 +2827,71 @@ class Engine {
             const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
             const u64 bpr = (((u64)nlocal * F * (w9 ? 2u : fb + 1) + 15) & ~15ull) + 16;
             const int nxt = cur ^ 1;
-            // ---- exchange: one all-gather per level ----------------------------------------------
-            if (multi) {
+            // ---- exchange: one all-gather per level, or (owner mode) columns to the owner and the union's child planes back -------
+            if (multi && !owner_mode) {
                 int rc = prm.allgather(prm.allgather_ctx, xsend, xrecv[xcur], (size_t)bpr, (void*)st);
                 if (rc) return fail(DSM_E_SINK, "allgather callback failed");
+                stats.exchange_bytes_sent += bpr;
+                stats.exchange_bytes_received += bpr * (u64)(world - 1);
+            }
+            const u32 nwv = (F + 63) >> 6;
+            const size_t bc_bytes = 16 + (size_t)nwv * 32;
+            if (owner_mode) {
+                if (prm.gather(prm.owner_ctx, owner, xsend, xrecv[xcur], (size_t)bpr, (void*)st)) return fail(DSM_E_SINK, "gather callback failed");
+                if (!is_owner) {
+                    // ---- a client of this prefix: wait for the owner's verdict on the level, then only the links of the next one ----
+                    stats.exchange_bytes_sent += bpr;
+                    if (prm.bcast(prm.owner_ctx, owner, bc_buf, bc_bytes, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
+                    stats.exchange_bytes_received += bc_bytes;
+                    u32 hdr[4] = {0, 0, 0, 0};
+                    DSM_HIP(hipMemcpyAsync(hdr, bc_buf, 16, hipMemcpyDeviceToHost, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                    if (hdr[0] == BC_CAPACITY) return fail(DSM_E_CAPACITY, "the prefix does not fit the owner's device arena: use a longer prefix or a larger arena_bytes");
+                    if (hdr[0] != BC_OK) return fail(DSM_E_HIP, "malformed broadcast from the prefix's owner");
+                    const u32 Fn = hdr[1] & 0x3FFFFFFFu;
+                    w16 = !(hdr[1] >> 31);
+                    w9 = w16 && !((hdr[1] >> 30) & 1u) && pack_columns;
+                    stats.union_nodes += depth >= 1 ? F : 0;
+                    if (F > stats.max_frontier) stats.max_frontier = F;
+                    ++stats.levels;
+                    if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+                    if (!Fn) break;
+                    const u64* planes = reinterpret_cast<const u64*>(bc_buf + 16);
+                    const u32 nbp = (F + TILE - 1) / TILE;
+                    if (nbp > 1) {
+                        hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, planes, nwv, cnt4, nbp);
+                        exclusive_scan<u32, u32>(cnt4, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
+                    }
+                    hipLaunchKernelGGL(lite_slot_kernel, dim3(nbp), dim3(256), 0, st, planes, F, cnt4, nbp, nbp == 1 ? 1u : 0u, lite_slot[nxt], Fcap);
+                    DSM_HIP(hipGetLastError());
+                    if (capture && depth + 1 == capture->depth) {  // (which bases continue the prefix: every rank enumerates the same sub-prefixes)
+                        std::vector<u32> hs(Fn);
+                        DSM_HIP(hipMemcpyAsync(hs.data(), lite_slot[nxt], (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
+                        DSM_HIP(hipStreamSynchronize(st));
+                        capture->sym.clear();
+                        capture->ord.clear();
+                        for (u32 v = 0; v < Fn; ++v) { capture->sym.push_back(hs[v] & 3u); capture->ord.push_back(std::vector<u16>(1, 0)); }
+                    }
+                    if (int rc = launch_expand(Fn, depth + 1, nxt, xcur ^ 1, w16, w9, lite_slot[nxt], fmt_in, false)) return rc;
+                    fmt_in = w16 && !trie_mode;
+                    cur = nxt;
+                    xcur ^= 1;
+                    F = Fn;
+                    ++depth;
+                    continue;
+                }
+                stats.exchange_bytes_received += bpr * (u64)(world - 1);
+                // the owner: whatever this level may allocate must fit before anything is sent back -- a failure later would leave the
+                // clients waiting.  (Emission-side allocations only flag a failure, see emit_failed.)
+                const size_t wc = (size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap;
+                const size_t need = wc * 12 + 512 + ((wc + TILE - 1) / TILE * 4) * 48 + 4096;
+                if (arena.off + need > arena.cap) {
+                    const u32 hdr[4] = {BC_CAPACITY, 0, 0, 0};
+                    DSM_HIP(hipMemcpyAsync(bc_buf, hdr, 16, hipMemcpyHostToDevice, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                    if (prm.bcast(prm.owner_ctx, owner, bc_buf, bc_bytes, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
+                    return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
+                }
             }
             Xchg x = xview(xcur, F, bpr);
             x.fb = fb;
@@ -2857,7 +2981,13 @@ class Engine {
                 pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 pa.packet = reinterpret_cast<uint4*>(h_totals + 304); pa.seq = ++pub_seq;
                 pa.next = spec_mode ? d_dyn : nullptr;
+                pa.bc_header = owner_mode ? reinterpret_cast<uint4*>(bc_buf) : nullptr;
                 hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, pa);
+            }
+            if (owner_mode) {  // the union's child planes of this level follow the header: what a client needs to go on
+                DSM_HIP(hipMemcpyAsync(bc_buf + 16, me.kplane, (size_t)nwv * 32, hipMemcpyDeviceToDevice, st));
+                if (prm.bcast(prm.owner_ctx, owner, bc_buf, bc_bytes, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
+                stats.exchange_bytes_sent += bc_bytes * (u64)(world - 1);
             }
             // ---- the next level's LF-step launch goes out now, sized on the device, assuming the level is of this level's frequency
             // class (the largest frequency only falls with depth: a prefix changes class twice); the host catches up below ----
@@ -2977,7 +3107,19 @@ class Engine {
                 if (rc == DSM_E_CAPACITY && multi) { emit_failed = true; ready = false; }
                 else if (rc) return rc;
             }
-            if (multi) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
+            if (owner_mode) {  // only the owner emits: its word on the emission side reaches the clients with one last broadcast
+                u32 hdr[4] = {emit_failed ? BC_CAPACITY : BC_OK, 0, 0, 0};
+                if (is_owner) {
+                    DSM_HIP(hipMemcpyAsync(bc_buf, hdr, 16, hipMemcpyHostToDevice, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                }
+                if (prm.bcast(prm.owner_ctx, owner, bc_buf, 16, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
+                if (!is_owner) {
+                    DSM_HIP(hipMemcpyAsync(hdr, bc_buf, 16, hipMemcpyDeviceToHost, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                }
+                if (hdr[0] != BC_OK) return fail(DSM_E_CAPACITY, "device arena exhausted on the prefix's owner: use a longer prefix or a larger arena_bytes");
+            } else if (multi) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
                 u64 ok = emit_failed ? 0 : 1, all_ok = 0;
                 if (int rc = agree_min(ok, &all_ok)) return rc;
                 if (!all_ok) return fail(DSM_E_CAPACITY, "device arena exhausted on a rank: use a longer prefix or a larger arena_bytes");
@@ -3341,7 +3483,7 @@ struct MinerT : MinerBase {
         int rc = 0;
         if (e.stream_mode) { e.sout.sink = bs; e.sout.psink = ps; e.sout.ctx = ctx; }
         for (int k = 0; k < n && !rc; ++k) {
-            const bool mine = !e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank;
+            const bool mine = e.owner_mode ? e.is_owner : (!e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank);
             e.stream_tag = k;
             if (e.stream_mode) rc = stream_auto(prefixes[k] ? prefixes[k] : "", ctx, 0, 0, 0, true, nullptr);
             else rc = run_auto(prefixes[k] ? prefixes[k] : "", ts, ctx, mine, 1, nullptr);

@@ -27,6 +27,11 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) get_id = nullptr;
     decltype(&ncclCommInitRank) init_rank = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
     decltype(&ncclCommDestroy) destroy = nullptr;
     decltype(&ncclGetErrorString) err_string = nullptr;
     std::string err;
@@ -41,9 +46,14 @@ struct RcclApi {
         get_id = (decltype(get_id))dlsym(lib, "ncclGetUniqueId");
         init_rank = (decltype(init_rank))dlsym(lib, "ncclCommInitRank");
         all_gather = (decltype(all_gather))dlsym(lib, "ncclAllGather");
+        send = (decltype(send))dlsym(lib, "ncclSend");
+        recv = (decltype(recv))dlsym(lib, "ncclRecv");
+        group_start = (decltype(group_start))dlsym(lib, "ncclGroupStart");
+        group_end = (decltype(group_end))dlsym(lib, "ncclGroupEnd");
+        broadcast = (decltype(broadcast))dlsym(lib, "ncclBroadcast");
         destroy = (decltype(destroy))dlsym(lib, "ncclCommDestroy");
         err_string = (decltype(err_string))dlsym(lib, "ncclGetErrorString");
-        if (!get_id || !init_rank || !all_gather || !destroy || !err_string) { err = "librccl lacks an expected symbol"; return false; }
+        if (!get_id || !init_rank || !all_gather || !destroy || !err_string || !send || !recv || !group_start || !group_end || !broadcast) { err = "librccl lacks an expected symbol"; return false; }
         return true;
     }
 };
@@ -71,6 +81,7 @@ struct dsm_rccl_gate {
 struct dsm_rccl {
     ncclComm_t comm = nullptr;
     int device = 0;
+    int world = 1, rank = 0;
     dsm_rccl_gate* gate = nullptr;
     int lane = 0;
 };
@@ -100,6 +111,8 @@ int dsm_rccl_create(const uint8_t* id, int world_size, int rank, int device, dsm
     dsm_rccl* c = new dsm_rccl();
     c->comm = comm;
     c->device = device;
+    c->world = world_size;
+    c->rank = rank;
     *out = c;
     return DSM_OK;
 }
@@ -132,6 +145,60 @@ int dsm_rccl_allgather(void* ctx, const void* sendbuf, void* recvbuf, size_t byt
         g->cv.notify_all();
     }
     return r == ncclSuccess ? 0 : 1;
+}
+
+// a lane's turn among the lanes of the process (see dsm_rccl_gate)
+namespace {
+struct Turn {
+    dsm_rccl_gate* g;
+    Turn(dsm_rccl* c) : g(c->gate) {
+        if (!g) return;
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->cv.wait(lk, [&] { return g->turn == c->lane; });
+    }
+    ~Turn() {
+        if (!g) return;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->advance();
+        }
+        g->cv.notify_all();
+    }
+};
+}  // namespace
+
+// dsm_gather_fn: every rank but the root sends its bytes to the root, which receives them rank-major (one ncclRecv per peer in a
+// group: the peers' messages arrive over their own links at the same time) and copies its own part in place.  One server per
+// prefix, one connection per client and prefix (metaenumerate.cpp:268-309, metaserver.cpp:682-728) -- between GPUs.
+int dsm_rccl_gather(void* ctx, int root, const void* sendbuf, void* recvbuf, size_t bytes, void* stream) {
+    dsm_rccl* c = (dsm_rccl*)ctx;
+    if (!c || !c->comm || root < 0 || root >= c->world) return 1;
+    Turn turn(c);
+    hipStream_t st = (hipStream_t)stream;
+    if (c->rank != root) return g_rccl.send(sendbuf, bytes, ncclUint8, root, c->comm, st) == ncclSuccess ? 0 : 1;
+    if (hipMemcpyAsync((uint8_t*)recvbuf + (size_t)root * bytes, sendbuf, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+    if (c->world == 1) return 0;
+    bool ok = g_rccl.group_start() == ncclSuccess;
+    for (int r = 0; r < c->world && ok; ++r)
+        if (r != root) ok = g_rccl.recv((uint8_t*)recvbuf + (size_t)r * bytes, bytes, ncclUint8, r, c->comm, st) == ncclSuccess;
+    return (g_rccl.group_end() == ncclSuccess && ok) ? 0 : 1;
+}
+// dsm_bcast_fn
+int dsm_rccl_bcast(void* ctx, int root, void* buf, size_t bytes, void* stream) {
+    dsm_rccl* c = (dsm_rccl*)ctx;
+    if (!c || !c->comm || root < 0 || root >= c->world) return 1;
+    Turn turn(c);
+    if (c->world == 1) return 0;
+    return g_rccl.broadcast(buf, buf, bytes, ncclUint8, root, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+int dsm_copy_from_device(void* host_dst, const void* device_src, size_t bytes, void* stream) {
+    if (hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return dsm::fail(DSM_E_HIP, "dsm_copy_from_device failed");
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? DSM_OK : dsm::fail(DSM_E_HIP, "dsm_copy_from_device failed");
+}
+int dsm_copy_to_device(void* device_dst, const void* host_src, size_t bytes, void* stream) {
+    if (hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return dsm::fail(DSM_E_HIP, "dsm_copy_to_device failed");
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? DSM_OK : dsm::fail(DSM_E_HIP, "dsm_copy_to_device failed");
 }
 
 void dsm_rccl_destroy(dsm_rccl* c) {

@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("max_frontier", C.c_uint64), ("expand_launches", C.c_uint64), ("expand_ms", C.c_double),
                 ("device_ms", C.c_double), ("host_ms", C.c_double), ("pair_order_exact", C.c_uint64), ("splits", C.c_uint64),
                 ("index_lines", C.c_uint64), ("records_read", C.c_uint64), ("record_bytes", C.c_uint64), ("expand_slots", C.c_uint64),
-                ("expand_column_bytes", C.c_uint64)]
+                ("expand_column_bytes", C.c_uint64), ("exchange_bytes_sent", C.c_uint64), ("exchange_bytes_received", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -52,6 +52,8 @@ BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 PREFIX_BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 TUPLE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TupleBatch))
 ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class Params(C.Structure):
@@ -59,7 +61,8 @@ class Params(C.Structure):
                 ("pmax", C.c_uint32), ("mindepth", C.c_uint32), ("emin", C.c_double), ("emax", C.c_double),
                 ("world_size", C.c_uint32), ("rank", C.c_uint32), ("allgather", ALLGATHER), ("allgather_ctx", C.c_void_p),
                 ("exchange_send", C.c_void_p), ("exchange_recv", C.c_void_p), ("exchange_bytes", C.c_uint64),
-                ("arena_bytes", C.c_uint64), ("wide", C.c_uint32), ("emit_owner_only", C.c_uint32), ("stream", C.c_void_p)]
+                ("arena_bytes", C.c_uint64), ("wide", C.c_uint32), ("emit_owner_only", C.c_uint32), ("stream", C.c_void_p),
+                ("owner_mode", C.c_uint32), ("owner_rank", C.c_uint32), ("gather", GATHER), ("bcast", BCAST), ("owner_ctx", C.c_void_p)]
 
 
 _lib = None
@@ -81,6 +84,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.dsm_last_error.restype = C.c_char_p
         L.dsm_abi_version.restype = C.c_int
+        L.dsm_copy_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dsm_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dsm_rccl_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dsm_rccl_bcast.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dsm_index_open_ex.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
         L.dsm_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.dsm_index_close.argtypes = [C.c_void_p]
@@ -244,7 +251,10 @@ def default_params():
 
 
 def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes, wide,
-                 stream, keep, emit_owner_only=0):
+                 stream, keep, emit_owner_only=0, owner_rank=None, owner_exchange=None):
+    """owner_rank (with owner_exchange): the prefixes of this miner are merged by that rank alone (dsm_params.owner_mode);
+    owner_exchange = an RcclComm (the library's ncclSend/Recv + ncclBroadcast) or an object with .gather(root, send_ptr, recv_ptr,
+    nbytes, stream) and .bcast(root, ptr, nbytes, stream)."""
     p = default_params()
     p.fmin, p.maxdepth, p.pmin, p.pmax, p.mindepth = fmin, maxdepth, pmin, pmax, mindepth
     p.emin, p.emax = emin, emax
@@ -271,6 +281,34 @@ def _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, r
         p.allgather = cb_ag
     if exchange is not None:
         p.exchange_send, p.exchange_recv, p.exchange_bytes = exchange
+    if owner_rank is not None:
+        p.owner_mode, p.owner_rank = 1, int(owner_rank)
+        if isinstance(owner_exchange, RcclComm):
+            p.gather = C.cast(lib().dsm_rccl_gather, GATHER)
+            p.bcast = C.cast(lib().dsm_rccl_bcast, BCAST)
+            p.owner_ctx = owner_exchange.h
+            keep.append(owner_exchange)
+        else:
+            def _ga(ctx, root, s_, r_, n, st):
+                try:
+                    owner_exchange.gather(root, s_, r_, n, st)
+                    return 0
+                except Exception:  # noqa: BLE001 - must not unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def _bc(ctx, root, b, n, st):
+                try:
+                    owner_exchange.bcast(root, b, n, st)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb_ga, cb_bc = GATHER(_ga), BCAST(_bc)
+            keep.extend([cb_ga, cb_bc])
+            p.gather, p.bcast = cb_ga, cb_bc
     return p
 
 
@@ -362,11 +400,11 @@ class Miner:
 
     def __init__(self, indexes, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0,
                  world_size=1, rank=0, allgather=None, exchange=None, arena_bytes=0, wide=0, stream=None, stream_mode=False,
-                 emit_owner_only=False):
+                 emit_owner_only=False, owner_rank=None, owner_exchange=None):
         self._keep = []
         self.indexes = list(indexes)
         p = _make_params(fmin, maxdepth, pmin, pmax, mindepth, emin, emax, world_size, rank, allgather, exchange, arena_bytes,
-                         wide, stream, self._keep, 1 if emit_owner_only else 0)
+                         wide, stream, self._keep, 1 if emit_owner_only else 0, owner_rank, owner_exchange)
         hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
         self.h = C.c_void_p()
         _check(lib().dsm_miner_create(hs, len(indexes), C.byref(p), 1 if stream_mode else 0, C.byref(self.h)))

@@ -130,3 +130,83 @@ class Exchange:
                 dist.all_gather_into_tensor(h_out, h_src, group=self.group)
                 out.copy_(h_out)
                 st.synchronize()
+
+
+    # ---- owner mode (dsm_gather_fn / dsm_bcast_fn): the columns go to the prefix's owner, the union's child planes come back ----
+    def _turn(self, fn):
+        if self.gate is not None:
+            self.gate.acquire(self.lane)
+            try:
+                fn()
+            finally:
+                self.gate.release(self.lane)
+        else:
+            fn()
+        self.calls += 1
+
+    def gather(self, root, send_ptr, recv_ptr, nbytes, stream=None):
+        """recv[half][r * nbytes : (r+1) * nbytes] on rank `root` = rank r's send[:nbytes]; the others only send."""
+        if send_ptr != self.send.data_ptr():
+            raise ValueError("send pointer is not the exchange send buffer")
+        if nbytes > self.nbytes:
+            raise ValueError("level larger than the exchange buffers")
+        off = self.half(recv_ptr)
+        self._turn(lambda: self._gather(root, nbytes, off))
+
+    def _gather(self, root, nbytes, off):
+        me = dist.get_rank(self.group)
+        src = self.send[:nbytes]
+        out = self.recv[off: off + nbytes * self.world]
+        if self.world == 1:
+            out.copy_(src)
+            return
+        st = self.stream if self.stream is not None else (torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None)
+        if self.backend == "nccl":
+            with torch.cuda.stream(st):
+                if me == root:
+                    out[root * nbytes:(root + 1) * nbytes].copy_(src)
+                    ops = [dist.P2POp(dist.irecv, out[r * nbytes:(r + 1) * nbytes], r, self.group) for r in range(self.world) if r != root]
+                else:
+                    ops = [dist.P2POp(dist.isend, src, root, self.group)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            self.bytes_moved += nbytes * (self.world - 1 if me == root else 1)
+            return
+        # gloo: through the host
+        if st is not None:
+            st.synchronize()
+        h_src = src.cpu()
+        if me == root:
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.gather(h_src, parts, dst=root, group=self.group)
+            out.copy_(torch.cat(parts))
+            if st is not None:
+                st.synchronize()
+        else:
+            dist.gather(h_src, None, dst=root, group=self.group)
+        self.bytes_moved += nbytes * (self.world - 1 if me == root else 1)
+
+    def bcast(self, root, ptr, nbytes, stream=None):
+        """nbytes at device pointer `ptr` (a buffer of the library) on rank `root` reach `ptr` on every rank."""
+        self._turn(lambda: self._bcast(root, ptr, nbytes, stream))
+
+    def _bcast(self, root, ptr, nbytes, stream):
+        import ctypes as C
+        from . import lib
+        if self.world == 1:
+            return
+        me = dist.get_rank(self.group)
+        if self.device.type == "cpu":
+            raise ValueError("owner mode needs device buffers")
+        h = torch.empty(nbytes, dtype=torch.uint8)
+        if me == root and lib().dsm_copy_from_device(h.data_ptr(), ptr, nbytes, stream):
+            raise RuntimeError("dsm_copy_from_device failed")
+        if self.backend == "nccl":
+            d = h.to(self.device)
+            dist.broadcast(d, src=root, group=self.group)
+            h = d.cpu()
+        else:
+            dist.broadcast(h, src=root, group=self.group)
+        if me != root and lib().dsm_copy_to_device(ptr, h.data_ptr(), nbytes, stream):
+            raise RuntimeError("dsm_copy_to_device failed")
+        self.bytes_moved += nbytes

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DSM_ABI_VERSION 2
+#define DSM_ABI_VERSION 3
 
 /* error codes (negative errno values) */
 #define DSM_OK 0
@@ -118,6 +118,10 @@ typedef struct dsm_stats {
     uint64_t record_bytes;   /* bytes of frontier records it read and wrote (compact 16-byte words, or the wide fields) */
     uint64_t expand_slots;   /* threads it ran = frontier nodes x local samples (absent nodes only cost their handle and column entry) */
     uint64_t expand_column_bytes; /* bytes of exchange column it wrote */
+    /* bytes this rank put on / took from the links in the per-level exchange (all-gather: its column out, the others' in;
+     * owner mode: columns to the owner, child masks back) */
+    uint64_t exchange_bytes_sent;
+    uint64_t exchange_bytes_received;
 } dsm_stats;
 
 /* ------------------------------------------------------------------------------------------------
@@ -177,6 +181,27 @@ void dsm_rccl_gate_retire(dsm_rccl_gate* g, int lane);
 void dsm_rccl_gate_reset(dsm_rccl_gate* g);
 void dsm_rccl_gate_destroy(dsm_rccl_gate* g);
 
+/* The reference's own partition between GPUs: ONE server per k-mer prefix merges every sample's stream
+ * (wrapper-SLURM/example-server.sh:27-41, metaserver.cpp:682-739), every client has one connection per prefix
+ * (metaenumerate.cpp:268-309).  With owner_mode the prefix of a miner is merged by rank owner_rank alone: per frontier level the
+ * other ranks SEND it their columns (gather) and get back only the union's child masks, 4 bits per node, with the level's width
+ * and frequency class (broadcast); reduce, scan, advance, reader-set orders, output predicates and candidate store run on the
+ * owner only.  A host keeps one miner per owner alive (lane j: owner_rank j, prefixes j, j + world, ...), so every rank is the
+ * server of one lane and a client in the others.
+ *   gather: rank root must end up with world_size * bytes_per_rank bytes at recvbuf, rank-major, its own part included (sendbuf
+ *           on root is its own contribution); the other ranks only send.
+ *   bcast:  bytes at buf on root reach buf on every rank.
+ * Device pointers, ordered on `stream` like dsm_allgather_fn. */
+typedef int (*dsm_gather_fn)(void* ctx, int root, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
+typedef int (*dsm_bcast_fn)(void* ctx, int root, void* buf, size_t bytes, void* stream);
+/* the same over RCCL (ncclSend / ncclRecv in one group; ncclBroadcast), ctx = the dsm_rccl* */
+/* for hosts that stage a device buffer of the library through host memory (backends without device-to-device transport):
+ * synchronous copies ordered after / before the work on `stream` */
+int dsm_copy_from_device(void* host_dst, const void* device_src, size_t bytes, void* stream);
+int dsm_copy_to_device(void* device_dst, const void* host_src, size_t bytes, void* stream);
+int dsm_rccl_gather(void* comm, int root, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
+int dsm_rccl_bcast(void* comm, int root, void* buf, size_t bytes, void* stream);
+
 typedef struct dsm_params {
     const char* prefix;      /* enforced path (hostinfo third column, metaenumerate.cpp:216); "" = whole trie */
     uint32_t fmin;           /* metaenumerate --fmin (default 10, metaenumerate.cpp:141) */
@@ -199,6 +224,12 @@ typedef struct dsm_params {
     uint32_t emit_owner_only;/* multi-rank dsm_miner_mine_many: prefix k is filtered and emitted only by rank k % world_size
                                 (every rank still expands its own samples for every prefix); 0 = every rank emits everything */
     void* stream;
+    /* owner mode (see dsm_gather_fn): all ranks pass the same owner_rank; allgather is still needed (creation-time agreement) */
+    uint32_t owner_mode;
+    uint32_t owner_rank;
+    dsm_gather_fn gather;
+    dsm_bcast_fn bcast;
+    void* owner_ctx;         /* ctx of gather and bcast */
 } dsm_params;
 
 void dsm_params_default(dsm_params* p);

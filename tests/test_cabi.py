@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), "libdsmhip.so does not export " + s
-    assert L.dsm_abi_version() == 2
+    assert L.dsm_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
