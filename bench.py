@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="independent prefix lanes (own stream, own communicator) that overlap one lane's "
                     "all-gather with the other's kernels; default 1 (N=1) / 2 (N>1)")
     ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
+    ap.add_argument("--exchange", choices=["allgather", "owner"], default=os.environ.get("DSM_BENCH_MODE", "allgather"),
+                    help="N > 1: 'allgather' = every rank merges every prefix from one all-gather per level; 'owner' = the reference's "
+                         "partition, prefix k is merged by rank k %% N alone (columns gathered to it, the union's child masks broadcast "
+                         "back), one lane per owner so that every rank is the server of one lane and a client in the others")
     ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
     return ap.parse_args()
 
@@ -335,7 +339,9 @@ def main():
     # One-letter prefixes at every N: a level costs a fixed ~50 us of launches (plus one all-gather when N > 1), and 16
     # two-letter prefixes have four times the levels (measured at N=1: 290 vs 353 ms per pass).  With more ranks than
     # prefixes some ranks emit nothing; that costs less than the extra levels.
-    plen = args.prefix_len if args.prefix_len >= 0 else 1
+    owner_mode = args.exchange == "owner" and (world > 1 or forced)
+    # owner mode wants at least as many prefixes as ranks (every rank the server of some prefix): two letters beyond four ranks
+    plen = args.prefix_len if args.prefix_len >= 0 else (2 if owner_mode and world > 4 else 1)
     prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
     pmin = args.pmin if args.pmin > 0 else (1 if world * args.nlocal == 1 else 2)
 
@@ -348,7 +354,9 @@ def main():
     # order on every rank (each lane issues the same number of collectives everywhere because every rank walks the same
     # union trie).  DSM_BENCH_LANES / --lanes override.
     nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 and not forced else "2"))
-    nlanes = max(1, min(nlanes, len(prefixes)))
+    if owner_mode:
+        nlanes = world  # lane j: the prefixes rank j serves
+    nlanes = max(1, min(nlanes, len(prefixes))) if not owner_mode else nlanes
     lanes = []
     gate = None
     # The exchange itself: by default the library's own (dsm_rccl_*: one RCCL communicator per lane, ncclAllGather from the C
@@ -397,7 +405,8 @@ def main():
         lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
                                     allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
                                     emit_owner_only=world > 1 or forced, arena_bytes=arena, wide=1 if args.wide else 0,
-                                    stream_mode=args.stream_mode)
+                                    stream_mode=args.stream_mode, owner_rank=j if owner_mode else None,
+                                    owner_exchange=(lane.get("rccl") or lane.get("ex")) if owner_mode else None)
         lanes.append(lane)
     if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
         for j, ln in enumerate(lanes):
@@ -407,7 +416,8 @@ def main():
                 ln["ex"].gate = gate
 
     tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
-           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0}
+           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0,
+           "xsent": 0, "xrecv": 0}
     import threading
     tot_lock = threading.Lock()
 
@@ -438,6 +448,8 @@ def main():
                     tot["record_bytes"] += st.record_bytes
                     tot["slots"] += st.expand_slots
                     tot["colbytes"] += st.expand_column_bytes
+                    tot["xsent"] += st.exchange_bytes_sent
+                    tot["xrecv"] += st.exchange_bytes_received
                     tot["splits"] = tot.get("splits", 0) + st.splits
                     tot["levels"] = tot.get("levels", 0) + st.levels
                     tot["max_frontier"] = max(tot.get("max_frontier", 0), st.max_frontier)
@@ -555,7 +567,9 @@ def main():
                                    "fmin=%d Emax=%g pmin=%d pmax=%d%s%s, %d prefixes" % (world * args.nlocal, args.reads, args.rlen, ix.n, args.nlocal, args.fmin, args.emax, pmin,
                                                                               args.pmax, ", 64-bit positions" if args.wide else "",
                                                                               ", wire-stream mode" if args.stream_mode else "", len(prefixes)),
-                       "parallelism": "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes),
+                       "parallelism": ("sample-per-gpu x%d, prefix k merged by rank k %% %d (columns gathered to it, child masks broadcast back), "
+                                       "%d lanes per GPU" % (world, world, nlanes)) if owner_mode else
+                                      "sample-per-gpu x%d, one all-gather per frontier level, %d prefix lane(s) per GPU" % (world, nlanes),
                        "exchange": ("none (single process)" if not (world > 1 or forced) else
                                     "dsm_rccl: ncclAllGather from the library's callback, one communicator per lane" if native else
                                     "torch.distributed all_gather_into_tensor (%s) from a Python callback" % dist.get_backend())},
@@ -591,6 +605,8 @@ def main():
                        "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
                        "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,
                        "format_ms_per_step": format_ms, "format_text_bytes_per_step": format_bytes,
+                       "exchange_bytes_sent_per_step_rank0": tot["xsent"] / max(1, args.steps),
+                       "exchange_bytes_received_per_step_rank0": tot["xrecv"] / max(1, args.steps),
                        "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps)},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)

@@ -2538,8 +2538,10 @@ class Engine {
             earena.cap = arena_b - arena.cap;
             ea = &earena;
         }
-        DSM_HIP(hipEventCreate(&ev0));
-        DSM_HIP(hipEventCreate(&ev1));
+        // (timing events without the system-scope fence a default event carries: the records bracket every LF-step launch, and a
+        // fence there would write the L2 back twice per level)
+        DSM_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableSystemFence));
+        DSM_HIP(hipEventCreateWithFlags(&ev1, hipEventDisableSystemFence));
         return 0;
     }
 
@@ -2578,7 +2580,7 @@ class Engine {
     hipEvent_t pool_event(size_t k) {
         while (evpool.size() <= k) {
             hipEvent_t e = nullptr;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
             evpool.push_back(e);
         }
         return evpool[k];
@@ -2687,7 +2689,9 @@ class Engine {
         const bool trace_levels = getenv("DSM_TRACE_LEVELS") != nullptr;  // debugging aid: widths of the levels on stderr
         bool fmt_in = false;  // format of the records of the level about to be expanded (the root's record is wide)
         // dynamic: F is not known yet (0 is passed): the kernel takes the width from d_dyn and runs only if the level's class is (w16, w9)
-        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, bool w9, const u32* lslot, bool fmt_in, bool dynamic) -> int {
+        // (dynamic launches: Fmax bounds the level -- four children per node of the level before it -- so a small level is not
+        // swept by the whole resident grid)
+        auto launch_expand = [&](u32 F, u32 depth, int cur, int xcur, bool w16, bool w9, const u32* lslot, bool fmt_in, bool dynamic, u64 Fmax = ~0ull) -> int {
             // ---- expand ---------------------------------------------------------------------------
             const u64 slots = (u64)F * 4;
             const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
@@ -2803,7 +2807,8 @@ class Engine {
                 const bool one_sb = (m.n >> SB_SHIFT) == 0;
                 P* cf = reinterpret_cast<P*>(es.valf);
                 u8* cl = es.pl;
-                const dim3 eg(dynamic ? expand_blocks : (need < expand_blocks ? need : expand_blocks));
+                const u64 dneed = Fmax == ~0ull ? (u64)expand_blocks : (Fmax + TILE - 1) / TILE;
+                const dim3 eg(dynamic ? (u32)(dneed < expand_blocks ? (dneed ? dneed : 1) : expand_blocks) : (need < expand_blocks ? need : expand_blocks));
                 u32* ecnt = (d == 1 && (ea.nbp > 1 || dynamic)) ? cntraw : (u32*)nullptr;
 #define DSM_LAUNCH_EXPAND(SB, IC, OC)                                                                                               \
     hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], \
@@ -2854,6 +2859,7 @@ class Engine {
                     stats.union_nodes += depth >= 1 ? F : 0;
                     if (F > stats.max_frontier) stats.max_frontier = F;
                     ++stats.levels;
+                    if (trace_levels) fprintf(stderr, "dsm level prefix=%s depth=%u F=%u (client of rank %d)\n", prefix.c_str(), depth, F, owner);
                     if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
                     if (!Fn) break;
                     const u64* planes = reinterpret_cast<const u64*>(bc_buf + 16);
@@ -2993,7 +2999,7 @@ class Engine {
             // class (the largest frequency only falls with depth: a prefix changes class twice); the host catches up below ----
             const bool spec = spec_mode;
             const bool spec_w16 = w16, spec_w9 = w9;
-            if (spec) { if (int rc = launch_expand(0, depth + 1, nxt, xcur ^ 1, spec_w16, spec_w9, new_slot2, fmt_in, true)) return rc; }
+            if (spec) { if (int rc = launch_expand(0, depth + 1, nxt, xcur ^ 1, spec_w16, spec_w9, new_slot2, fmt_in, true, (u64)F * 4)) return rc; }
             u32 pk[4];
             {   // the publish kernel is the last work queued: its packet in pinned memory is this level's completion.  Spinning on
                 // it returns a few microseconds after the store; a stream synchronisation wakes the thread later.

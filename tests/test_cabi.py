@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert (p.fmin, p.pmin, p.pmax, p.maxdepth, p.world_size) == (10, 2, 0, 0xFFFFFFFF, 1)
     assert p.emax == -1.0 and p.emin == 0.0
     assert C.sizeof(pydsm.Code) == 16
-    assert C.sizeof(pydsm.Stats) == 20 * 8
+    assert C.sizeof(pydsm.Stats) == 22 * 8
 
 
 def test_no_cpu_fallback_without_gpu(golden):

@@ -147,6 +147,102 @@ def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cf
         assert sum(reported[p]) == want
 
 
+def _owner_worker(rank, world, port, q, fmis, prefixes, kw, arena):
+    """Owner mode as a host drives it: one miner (lane) per owner, every rank the server of lane `rank` and a client in the others;
+    the lanes run on their own threads and streams, their collectives ordered by a TurnGate (same order on every rank)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "dsm-framework_amd"))
+    _init(rank, world, port)
+    import pydsm
+    from pydsm.dist import Exchange, TurnGate
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    nloc = len(fmis) // world
+    idx = [pydsm.Index(f, device=0) for f in fmis[rank * nloc:(rank + 1) * nloc]]
+    gate = TurnGate(world)
+    lanes = []
+    for j in range(world):  # creation runs collectives: lane by lane, in the same order on every rank
+        st = torch.cuda.Stream(device=dev)
+        ex = Exchange(1 << 22, world, dev, stream=st, lane=j)
+        m = pydsm.Miner(idx, world_size=world, rank=rank, allgather=ex.allgather, exchange=ex.params(), stream=st.cuda_stream,
+                        owner_rank=j, owner_exchange=ex, arena_bytes=arena, **kw)
+        lanes.append((st, ex, m))
+    for st, ex, m in lanes:
+        ex.gate = gate
+    res = [None] * world
+    errs = []
+
+    def run(j):
+        st, ex, m = lanes[j]
+        gate.begin(j)
+        try:
+            with torch.cuda.stream(st):
+                text, stt = m.mine_many(prefixes[j::world])
+            res[j] = (text, stt.reported, stt.union_nodes, stt.splits, stt.exchange_bytes_sent, stt.exchange_bytes_received, stt.tuples)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+        finally:
+            gate.retire(j)
+    ths = [threading.Thread(target=run, args=(j,)) for j in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(240)
+    q.put((rank, res, errs))
+    if errs:
+        os._exit(1)  # (the other ranks may be blocked in a collective)
+    for st, ex, m in lanes:
+        m.close()
+    for ix in idx:
+        ix.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname,world,cfg,arena", [("toy3", 3, "default", 0), ("toy3", 3, "default", 5 << 20), ("five", 5, "default", 0),
+                                                      ("many30", 5, "p3", 0)])   # (fewer prefixes than ranks: some lanes stay idle)
+def test_owner_mode_one_server_per_prefix(golden, setname, world, cfg, arena):
+    """The reference's partition (one metaserver per prefix, wrapper-SLURM/example-server.sh:27-41; one client connection per
+    prefix, metaenumerate.cpp:268-309) between ranks: prefix k is merged by rank k % world alone, the others send it their
+    columns and get the union's child masks back.  Tuples of every prefix equal the reference server's stdout; a client receives
+    far fewer bytes than it sends; a budget of a few MiB makes owner and clients split the same prefixes."""
+    from goldenlib import server_args_to_kw
+    m = golden.manifest["sets"][setname]
+    fmis = [golden.fmi(setname, n) for n in m["names"]]
+    kw = server_args_to_kw(m["server_cfgs"][cfg])
+    kw["fmin"] = m["fmin"]
+    if "maxdepth" in m:
+        kw["maxdepth"] = m["maxdepth"]
+    prefixes = {"toy3": ["A", "GT", "C", "T", "G", "AC", "TTG"], "five": ["A", "C", "G", "T"], "many30": ["AC", "G"]}[setname]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    nloc = len(fmis) // world
+    ps = [ctx.Process(target=_owner_worker, args=(r, world, port, q, fmis, prefixes, kw, arena * nloc)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    splits = {}
+    for rank, lanes, errs in res:
+        assert not errs, errs
+        for j, (text, reported, union, nsplit, sent, received, tuples) in enumerate(lanes):
+            mine = b"".join(golden.server_out(setname, cfg, p) for p in prefixes[j::world])
+            if not prefixes[j::world]:
+                assert text == b"" and sent == received == 0
+            elif j == rank:  # the server of this lane
+                assert text == mine, (rank, j)
+                assert received > sent > 0
+            else:          # a client: it emits nothing, sends its columns and receives the masks
+                assert text == b"" and tuples == 0
+                assert sent > received > 0
+            splits.setdefault(j, set()).add(nsplit)
+    assert all(len(v) == 1 for v in splits.values())  # owner and clients split the same prefixes
+    if arena:
+        assert sum(next(iter(v)) for v in splits.values()) > 0, "the small budget was meant to force prefix splits"
+
+
 def test_turn_gate_interleaves_lanes_deterministically():
     """Two lane threads with different numbers of collectives: the global order is strict round-robin while both are active."""
     import threading
@@ -273,14 +369,24 @@ def test_bench_two_ranks_sharing_the_card_over_gloo(tmp_path):
     import json
     import subprocess
     env = dict(os.environ, DSM_BENCH_DIR=str(tmp_path), DSM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu",
-           "--reads", "200000", "--genome", "1000000"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    def launch(extra):
+        for attempt in range(3):  # (a port picked here can be taken again before the launcher binds it)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu",
+                   "--reads", "200000", "--genome", "1000000"] + extra
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+                break
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    d = launch([])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["exchange"].startswith("torch.distributed") and "2 prefix lane(s)" in d["config"]["parallelism"]
     assert d["detail"]["union_nodes_per_step"] > d["detail"]["rank0_nodes_per_step"] > 0   # two samples: the union trie is larger than one sample's
+    # the same launch line in owner mode: prefix k merged by rank k % 2 alone, one lane per owner; same nodes, same tuples
+    o = launch(["--exchange", "owner"])
+    assert "merged by rank k % 2" in o["config"]["parallelism"] and o["n_gpus"] == 2
+    assert o["detail"]["rank0_nodes_per_step"] == d["detail"]["rank0_nodes_per_step"]  # (union_nodes depends on how prefixes were split)
+    assert o["value"] > 0 and o["detail"]["exchange_bytes_sent_per_step_rank0"] > 0

@@ -1,0 +1,71 @@
+"""Round-3 roofline evidence.
+  make_traffic.py trace <kernel_trace.csv> STEPS WARMUP
+      -> per-pass total of ALL expand_kernel instantiations over the timed passes and the average per REAL launch
+         (the launches queued ahead that found another frequency class return at once: they are counted, not averaged in)
+  make_traffic.py traffic <pmc_agg lines> <bench json> <trace summary json>
+      -> profiles/traffic.json: HBM bytes per LF-step launch = FETCH_SIZE + 1/2 x (coalesced record and handle reads, known
+         exactly from the kernel's counters) + WRITE_SIZE (MI355X_MICROARCH.md: FETCH_SIZE counts a 128-byte request as 64 bytes;
+         calibrated in round 1 with tools/gather_calib: random 64-byte reads factor 1.00, streaming reads 0.50)"""
+import csv
+import json
+import sys
+
+
+def trace(path, steps, warm):
+    rows = [r for r in csv.DictReader(open(path)) if "expand_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
+    passes = steps + warm
+    per = len(dur) // passes
+    timed = dur[per * warm:]
+    noop = [d for d in timed if d < 2500]          # a launch that only compares two words: 1.3 us
+    real = [d for d in timed if d >= 2500]
+    out = {"expand_launches_per_pass_total": per, "noop_launches_per_pass": len(noop) / steps, "real_launches_per_pass": len(real) / steps,
+           "rocprof_expand_ms_per_step": sum(timed) / steps / 1e6, "rocprof_avg_launch_ms": sum(real) / max(1, len(real)) / 1e6,
+           "steps": steps, "warmup": warm}
+    print(json.dumps(out))
+
+
+def traffic(pmc_path, bench_path, trace_path):
+    agg = {}
+    for line in open(pmc_path):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        for k, v in json.loads(line).items():
+            name, counter = k.rsplit("|", 1)
+            if "expand_kernel" in name:
+                agg.setdefault(counter, [0.0, 0])
+                agg[counter][0] += v["sum"]
+                agg[counter][1] += v["n"]
+    bench = json.loads([ln for ln in open(bench_path) if ln.startswith("{")][-1])
+    tr = json.loads(open(trace_path).read())
+    launches = bench["roofline"]["launches"] // bench["steps"]
+    nodes = bench["detail"]["rank0_nodes_per_step"]
+    fetch = agg["FETCH_SIZE"][0] * 1024.0   # KiB
+    write = agg["WRITE_SIZE"][0] * 1024.0
+    known = 20.0 * nodes                    # 16-byte compact record + 4-byte handle per node read, coalesced
+    per_step = fetch + 0.5 * known + write
+    hit, miss = agg.get("TCC_HIT_sum", [0, 0])[0], agg.get("TCC_MISS_sum", [0, 0])[0]
+    out = {"round": 3, "reads": 10000000, "prefix_len": 1, "gpus": 1, "kernel": "expand_kernel<u32,...> (all record-format variants)",
+           "launches": launches, "FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write, "coalesced_read_bytes_known": known,
+           "correction": "gfx950 FETCH_SIZE counts 128-B coalesced requests at 64 B (calibrated in round 1 with tools/gather_calib: random "
+                         "64-B block reads factor 1.00, streaming reads factor 0.50); traffic = FETCH + 0.5*known coalesced reads (16-byte "
+                         "compact record + 4-byte handle per node) + WRITE",
+           "bytes_per_step": per_step, "bytes_per_launch": per_step / launches,
+           "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
+           "rocprof_avg_launch_ms": tr["rocprof_avg_launch_ms"], "rocprof_expand_ms_per_step": tr["rocprof_expand_ms_per_step"],
+           "bench_avg_launch_ms_same_box": bench["roofline"]["avg_launch_ms"],
+           "bench_expand_ms_per_step_same_box": bench["detail"]["expand_ms_per_step"],
+           "pmc_launches_seen": agg["FETCH_SIZE"][1],
+           "sq": {k: v[0] for k, v in agg.items() if k.startswith("SQ_")},
+           "source": "tools/profiling/r03_final.sh on one box: bench.py --steps 3 --warmup 1 (JSON line and kernel trace), then one "
+                     "rocprofv3 --pmc pass per counter group of bench.py --steps 1 --warmup 0 --no-cpu --no-extras"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
