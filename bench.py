@@ -519,7 +519,7 @@ def main():
     # text formatting is outside the timed region (the sink receives binary batches): one more pass, untimed as a whole, in which
     # only the calls of dsm_format_batch (metaserver.cpp:472-484's printf loop, multi-threaded in the library) are timed
     format_ms, format_bytes = None, 0
-    if rank == 0 and world == 1 and not args.stream_mode and not forced:
+    if rank == 0 and world == 1 and not args.stream_mode and not forced and not args.no_cpu:  # (--no-cpu: profiling runs, exactly steps + warmup passes)
         import ctypes as C
         acc = {"s": 0.0, "bytes": 0}
 

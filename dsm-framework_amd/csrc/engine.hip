@@ -862,6 +862,7 @@ __device__ __forceinline__ bool filter_node(const FilterArgs& a, const Xchg& x, 
 // advance sweep (the lane of parent u reads word u, coalesced), and the path of a candidate of level l is put together from
 // (l + 15) / 16 words instead of l parent links: one random 64-byte line per 16 symbols instead of one per symbol.
 constexpr u32 PW_CHUNK = 16;
+constexpr u32 SREC_FIRST = 4u, SREC_LAST = 8u;  // flag bits of a stream record's second word (see keep_kernel)
 __device__ __forceinline__ uint2 child_path_word(const uint2 parent, u32 u, u32 plevel, u32 c) {
     const u32 r = plevel & (PW_CHUNK - 1);
     return r == 0 ? make_uint2(u, c) : make_uint2(parent.x, parent.y | (c << (2 * r)));
@@ -869,6 +870,7 @@ __device__ __forceinline__ uint2 child_path_word(const uint2 parent, u32 u, u32 
 
 struct AdvanceOut {
     u32* slot;        // retained: 4*parent + sym of every new node (null: nobody reads the links -- mining without derived handles)
+    uint4* srec;      // stream mode: the new nodes' records (parent and symbol / first / last flags are written here, see keep_kernel)
     uint2* pw;        // retained path words of the new nodes (null: stream mode); pw_after_slot: they follow the slot array, whose length
     const uint2* parent_pw;  // (the new level's width) only the device knows when this sweep runs -- *width, or the single tile's total
     const u32* width;
@@ -1013,6 +1015,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
             if (((pres >> c) & 1u) && vj[c] < o.cap) {  // a level wider than its arrays is reported through the total, not written
                 if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
                 if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
+                if (o.srec) reinterpret_cast<uint2*>(o.srec + vj[c])[0] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
                 if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
             }
         }
@@ -1158,6 +1161,7 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
         if (((pres >> c) & 1u) && vj[c] < o.cap) {
             if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
             if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
+            if (o.srec) reinterpret_cast<uint2*>(o.srec + vj[c])[0] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
             if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
         }
     }
@@ -1457,13 +1461,15 @@ __global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, c
     }
 }
 
-// stream mode (one sample): frequency and left char of every node of the level are retained for the wire stream
+// stream mode (one sample): a level retains one 16-byte record per node for the wire stream:
+//   .x parent index, .y symbol | first-child << 2 | last-child << 3 (written by the advance sweep of the parent's level),
+//   .z/.w frequency | left-char code << 61 (written here, when the node's own level has been expanded)
 template <typename P>
-__global__ void keep_kernel(u32 F, Xchg x, P* __restrict__ freq, u8* __restrict__ left) {
+__global__ void keep_kernel(u32 F, Xchg x, uint4* __restrict__ srec) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
-    freq[v] = x_freq<P>(x, 0, v);
-    left[v] = (u8)(x_pl<P>(x, 0, v) >> 4);
+    const u64 w = (u64)x_freq<P>(x, 0, v) | ((u64)(x_pl<P>(x, 0, v) >> 4) << 61);
+    reinterpret_cast<uint2*>(srec + v)[1] = make_uint2((u32)w, (u32)(w >> 32));
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
@@ -1670,6 +1676,14 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
 }
 
 // ---- wire stream (ClientSocket.h:20-39) ---------------------------------------------------------
+// The stream is the depth-first serialisation  node := '(' sym node* varint(freq) ['R' varint(count)]{depth<=6} leftchar ')'.
+// Cut at the leaves it is a sequence of CHUNKS, one per leaf in trie order: the opening tokens of the leaf's "open run" (the leaf
+// and its ancestors as long as each is the FIRST child of its parent: their '(' sym tokens are adjacent in the stream), then the
+// closing tokens of its "close run" (the leaf and its ancestors as long as each is the LAST child).  Every node is in exactly one
+// open run and one close run.  So: leaves per subtree bottom-up, then top-down the rank of every leaf and the sizes of its two
+// runs, a scan over the leaves for the chunk offsets, and one thread per leaf that walks up its runs -- one dependent read per
+// node -- and writes its chunk front to back: neighbouring threads write neighbouring bytes.  (A node-per-thread scatter of the
+// two tokens wrote two partial lines per node into the multi-GB buffer.)
 __device__ __forceinline__ u32 varint_len(u64 u) {
     if (u < 128) return 1;
     return 1 + (u32)((64 - __clzll((long long)u) + 7) >> 3);
@@ -1681,50 +1695,175 @@ __device__ __forceinline__ u32 put_varint(u8* p, u64 u) {
     for (u32 k = 0; k < l; ++k) p[1 + k] = (u8)(u >> (8 * k));
     return 1 + l;
 }
+constexpr u64 SREC_FREQ_MASK = (1ull << 61) - 1;
+__device__ __forceinline__ u64 srec_word(const uint4& r) { return ((u64)r.w << 32) | r.z; }
 
-// own bytes of a node: '(' sym + varint(freq) + ['R' varint(reported)] + left + ')'
-template <typename P>
-__global__ void stream_own_kernel(u32 F, u32 depth, u64 rbase, const P* __restrict__ freq, const u64* __restrict__ pre, const u64* __restrict__ sz,
-                                  u64* __restrict__ own) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= F) return;
-    u64 b = 2 + varint_len((u64)freq[v]) + 2;
-    if (depth <= 6) b += 1 + varint_len(rbase + pre[v] + sz[v]);  // EnumerateQuery.cpp:214-218
-    own[v] = b;
+// bottom-up: leaves in the subtree (a node without children is one)
+__global__ __launch_bounds__(256) void stream_leaves_kernel(u32 F, Kids kids, const u32* __restrict__ child_lf, u32* __restrict__ lf) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6, stride = gridDim.x * 4;
+    const u32 w0 = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    KidWave kw[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, wc = w < nw ? w : 0u;
+        if (child_lf) kid_wave(kids, wc, kw[i]);
+    }
+    u32 s[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) s[i] = 0;
+    if (child_lf) {
+        u32 g[NPT][4];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[i][c] = child_lf[((kw[i].p[c] >> lane) & 1) ? kw[i].c[c] + bits_below_lane(kw[i].p[c]) : 0u];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[i] += ((kw[i].p[c] >> lane) & 1) ? g[i][c] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const u32 w = w0 + (u32)i * stride, v = w * 64 + lane;
+        if (w < nw && v < F) lf[v] = s[i] ? s[i] : 1u;
+    }
 }
 
-// The two tokens of a node: '(' sym at its offset, and varint(freq) ['R' varint(count)] left ')' after its subtree.  Below depth 6
-// the closing token is at most eight bytes for frequencies under 2^32: it is put together in a register and stored as 4 + 2 + 1
-// byte pieces (the addresses have no alignment: the target allows that for global memory) instead of byte by byte.
-template <typename P>
-__global__ void stream_write_kernel(u32 F, u32 depth, u64 rbase, const u32* __restrict__ slot, const P* __restrict__ freq, const u8* __restrict__ left,
-                                    const u64* __restrict__ pre, const u64* __restrict__ sz, const u64* __restrict__ off, const u64* __restrict__ bytes,
-                                    const u64* __restrict__ own, u8* __restrict__ out) {
-    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= F) return;
-    u8* p = out + off[v];
-    const unsigned short head = (unsigned short)('(' | ((0x54474341u >> (8 * (slot[v] & 3))) & 0xFFu) << 8);
-    __builtin_memcpy(p, &head, 2);
-    const u64 f = (u64)freq[v];
-    const u32 lc = (0x4E54474341300000ull >> (8 * (left[v] + 2))) & 0xFFu;  // "0ACGTN"[left]
-    if (depth > 6 && f < (1ull << 32)) {
-        u64 tok;
-        u32 n;
-        if (f < 128) { tok = f | 0x80; n = 1; }
-        else { const u32 l = (u32)((64 - __clzll((long long)f) + 7) >> 3); tok = (u64)l | (f << 8); n = 1 + l; }
-        tok |= ((u64)lc | ((u64)')' << 8)) << (8 * n);
-        n += 2;
-        u8* q = p + bytes[v] - n;
-        if (n & 4) { const u32 w = (u32)tok; __builtin_memcpy(q, &w, 4); q += 4; tok >>= 32; }
-        if (n & 2) { const unsigned short w = (unsigned short)tok; __builtin_memcpy(q, &w, 2); q += 2; tok >>= 16; }
-        if (n & 1) *q = (u8)tok;
+// What travels top-down: per node the rank of its first leaf, and what it inherits from its parent -- the length of the open run
+// above it (0 unless it is a first child) and the bytes of the close run above it (0 unless it is a last child).
+struct StreamDown {
+    u32 F, level;
+    const u32* rank;      // this level: [F]
+    const u32* kin;
+    const u32* cin;
+    u32* rank_n;          // next level
+    u32* kin_n;
+    u32* cin_n;
+    const uint4* srec;    // this level's records (null at level 0: the root is not a node of the stream)
+    const u32* child_lf;  // leaves per subtree of the next level (null: this is the last level)
+    Kids kids;
+    u64* leaf_id;         // per leaf rank: level << 32 | node
+    u32* chunk;           // bytes of the leaf's chunk ('R' tokens of the nodes above depth 6 are added later)
+    u32* kop;             // length of its open run
+    u32* top_rank;        // levels 1..6: rank of the node's first leaf and its number of leaves (for the 'R' tokens), may be null
+    u32* top_lf;
+    const u32* lf;        // this level's leaves per subtree
+};
+__global__ __launch_bounds__(256) void stream_down_kernel(StreamDown a) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (a.F + 63) >> 6;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    if (w >= nw) return;
+    const u32 v = w * 64 + lane;
+    const bool in = v < a.F;
+    const u32 vc = in ? v : 0u;
+    KidWave kw;
+    u32 m = 0;
+    if (a.child_lf) {
+        kid_wave(a.kids, w, kw);
+        m = (u32)((kw.p[0] >> lane) & 1) | ((u32)((kw.p[1] >> lane) & 1) << 1) | ((u32)((kw.p[2] >> lane) & 1) << 2) | ((u32)((kw.p[3] >> lane) & 1) << 3);
+    }
+    const u32 rank = a.rank[vc], kin = a.kin[vc], cin = a.cin[vc];
+    u64 fw = 0;
+    if (a.srec) fw = srec_word(a.srec[vc]);
+    u32 g[3] = {0, 0, 0};
+    if (a.child_lf) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool need = ((m >> c) & 1u) && (m >> (c + 1)) != 0;  // a child's leaves matter only when a later sibling exists
+            g[c] = a.child_lf[need ? kw.c[c] + bits_below_lane(kw.p[c]) : 0u];
+        }
+    }
+    if (!in) return;
+    const u32 kopen = a.level >= 1 ? kin + 1 : 0u;                                                   // open run down to and including this node
+    const u32 cb = a.level >= 1 ? cin + varint_len(fw & SREC_FREQ_MASK) + 2u : 0u;                   // close run: varint(freq) left ')'
+    if (a.top_rank) { a.top_rank[v] = rank; a.top_lf[v] = a.lf[v]; }
+    if (!m) {  // a leaf: its chunk
+        if (a.level >= 1) {
+            a.leaf_id[rank] = ((u64)a.level << 32) | v;
+            a.chunk[rank] = 2u * kopen + cb;
+            a.kop[rank] = kopen;
+        }
         return;
     }
-    u8* q = p + bytes[v] - (own[v] - 2);
-    q += put_varint(q, f);
-    if (depth <= 6) { *q++ = 'R'; q += put_varint(q, rbase + pre[v] + sz[v]); }
-    *q++ = (u8)lc;
-    *q = ')';
+    const u32 firstc = (u32)__ffs((int)m) - 1u, lastc = 31u - (u32)__clz((int)m);
+    u32 r = rank;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if ((m >> c) & 1u) {
+            const u32 ch = kw.c[c] + bits_below_lane(kw.p[c]);
+            a.rank_n[ch] = r;
+            a.kin_n[ch] = (u32)c == firstc ? kopen : 0u;
+            a.cin_n[ch] = (u32)c == lastc ? cb : 0u;
+            if (c < 3) r += g[c];
+        }
+    }
+}
+
+// 'R' tokens (EnumerateQuery.cpp:214-218): a node of depth <= 6 sends the number of nodes reported when its subtree is done =
+// the nodes opened by the chunks up to its last leaf (every node's '(' is in exactly one chunk, and chunks are in stream order).
+// cumk[r] = open-run lengths of the leaves before r.  The token belongs to the chunk of the node's LAST leaf.
+__global__ void stream_rtok_kernel(u32 F, u64 rbase, const u32* __restrict__ top_rank, const u32* __restrict__ top_lf, const u64* __restrict__ cumk,
+                                   const u32* __restrict__ kop, u32 nleaf, u64* __restrict__ rval, u32* __restrict__ chunk) {
+    u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= F) return;
+    const u32 last = top_rank[v] + top_lf[v] - 1;
+    const u64 val = rbase + cumk[last] + kop[last];
+    rval[v] = val;
+    atomicAdd(&chunk[last], 1u + varint_len(val));
+}
+
+// one thread per leaf, in trie order: the chunk, front to back
+constexpr u32 STREAM_LDS_LEVELS = 1024;
+__global__ __launch_bounds__(256) void stream_chunk_kernel(u32 nleaf, u32 nlev, const uint4* const* __restrict__ srec_tab, const u64* const* __restrict__ rval_tab,
+                                                           const u64* __restrict__ leaf_id, const u64* __restrict__ chunk_off, const u32* __restrict__ kop,
+                                                           u8* __restrict__ out) {
+    __shared__ const uint4* s_rec[STREAM_LDS_LEVELS];
+    const u32 nl = nlev < STREAM_LDS_LEVELS ? nlev : STREAM_LDS_LEVELS;
+    for (u32 q = threadIdx.x; q < nl; q += blockDim.x) s_rec[q] = srec_tab[q];
+    __syncthreads();
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nleaf) return;
+    const u64 id = leaf_id[r];
+    u32 l = (u32)(id >> 32), v = (u32)id;
+    const u32 ko = kop[r];
+    u8* po = out + chunk_off[r] + 2ull * ko;  // the opening tokens end here (written back to front: the walk goes up)
+    u8* pc = po;                              // the closing tokens start here
+    bool inopen = true, inclose = true;
+    while (l >= 1 && (inopen || inclose)) {
+        const uint4 rec = (l < STREAM_LDS_LEVELS ? s_rec[l] : srec_tab[l])[v];
+        if (inopen) {
+            po -= 2;
+            const unsigned short head = (unsigned short)('(' | ((0x54474341u >> (8 * (rec.y & 3u))) & 0xFFu) << 8);
+            __builtin_memcpy(po, &head, 2);
+            if (!(rec.y & SREC_FIRST)) inopen = false;
+        }
+        if (inclose) {
+            const u64 fw = srec_word(rec);
+            const u64 f = fw & SREC_FREQ_MASK;
+            const u32 lc = (0x4E54474341300000ull >> (8 * ((u32)(fw >> 61) + 2))) & 0xFFu;  // "0ACGTN"[left]
+            if (l > 6 && f < (1ull << 32)) {  // at most eight bytes: put together in a register, stored as 4 + 2 + 1 byte pieces
+                u64 tok;
+                u32 n;
+                if (f < 128) { tok = f | 0x80; n = 1; }
+                else { const u32 ln = (u32)((64 - __clzll((long long)f) + 7) >> 3); tok = (u64)ln | (f << 8); n = 1 + ln; }
+                tok |= ((u64)lc | ((u64)')' << 8)) << (8 * n);
+                n += 2;
+                if (n & 4) { const u32 wv = (u32)tok; __builtin_memcpy(pc, &wv, 4); pc += 4; tok >>= 32; }
+                if (n & 2) { const unsigned short wv = (unsigned short)tok; __builtin_memcpy(pc, &wv, 2); pc += 2; tok >>= 16; }
+                if (n & 1) { *pc = (u8)tok; pc += 1; }
+            } else {
+                pc += put_varint(pc, f);
+                if (l <= 6) { *pc++ = 'R'; pc += put_varint(pc, rval_tab[l][v]); }
+                *pc++ = (u8)lc;
+                *pc++ = ')';
+            }
+            if (!(rec.y & SREC_LAST)) inclose = false;
+        }
+        v = rec.x;
+        --l;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1758,13 +1897,11 @@ struct LevelHost {
     u64* freqs = nullptr;
     u32* sub = nullptr;
     // stream
-    void* freq = nullptr;
-    u8* left = nullptr;
-    u64* sz = nullptr;
-    u64* pre = nullptr;
-    u64* own = nullptr;
-    u64* bytes = nullptr;
-    u64* off = nullptr;
+    uint4* srec = nullptr;      // per node: parent, symbol and first / last flags, frequency and left char (keep_kernel)
+    u32* lf = nullptr;          // leaves in the subtree
+    u32* top_rank = nullptr;    // levels 1..6: rank of the first leaf, leaves, value of the 'R' token
+    u32* top_lf = nullptr;
+    u64* rval = nullptr;
 };
 
 static inline dim3 grid_for(u64 n, int t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
@@ -2906,13 +3043,8 @@ class Engine {
             LevelHost child;
             // the arena hands out memory past `off`; the new level's arrays are claimed after Fn is known, so
             // the down-sweep writes into a provisional window that is then committed
-            if (stream_mode && depth >= 1) {  // this level's own frequencies / left chars go to the wire stream
-                P* fq;
-                ARENA_GET(fq, P, F);
-                ARENA_GET(me.left, u8, F);
-                me.freq = fq;
-                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, fq, me.left);
-            }
+            if (stream_mode && depth >= 1)  // this level's own frequencies / left chars complete its records for the wire stream
+                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, me.srec);
             const bool emit_here = !stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi;
             bool filtered = false;
             if (emit_here) {
@@ -2925,15 +3057,16 @@ class Engine {
             // What a level retains per node: the links (4 * parent + symbol) where something reads them -- the wire stream, handles
             // derived inside the LF-step kernel -- and the path words when tuples are mined.  With both, the words follow the links,
             // whose length only the device knows when the sweep runs: the window is sized for the widest level possible here.
-            const bool keep_slot = stream_mode || self_mode, keep_pw = !stream_mode;
+            const bool keep_slot = self_mode, keep_pw = !stream_mode, keep_srec = stream_mode;  // (stream mode: one 16-byte record per node)
             const size_t wcap = (size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap;
-            u8* window = arena.get<u8>(wcap * ((keep_slot ? 4 : 0) + (keep_pw ? 8 : 0)) + 512);
+            u8* window = arena.get<u8>(wcap * ((keep_slot ? 4 : 0) + (keep_pw ? 8 : 0) + (keep_srec ? 16 : 0)) + 512);
             if (!window) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
             u32* new_slot2 = keep_slot ? reinterpret_cast<u32*>(window) : nullptr;
             const u32 nbp = (F + TILE - 1) / TILE;  // tiles of this level
             AdvanceOut ao;
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.nT = nT[nxt]; ao.samechild = samechild;
+            if (keep_srec) ao.srec = reinterpret_cast<uint4*>(window);
             if (keep_pw) {
                 ao.pw = reinterpret_cast<uint2*>(window);  // (behind the links: the kernels place it, see pw_after_slot)
                 ao.pw_after_slot = keep_slot ? 1u : 0u;
@@ -3030,6 +3163,7 @@ class Engine {
             if (Fn) {
                 if (keep_slot) child.slot = arena.get<u32>(Fn);   // same address as new_slot2
                 if (keep_pw) child.pw = arena.get<uint2>(Fn);     // the window's start, or right behind the links (256-byte granules, as the kernels assume)
+                if (keep_srec) child.srec = arena.get<uint4>(Fn);
                 if (int rc = alloc_kids(child)) return rc;
                 if (spec_hit) {
                     stats.expand_slots += Fn;
@@ -3061,7 +3195,12 @@ class Engine {
                 std::vector<u32> hs(Fn);
                 std::vector<u16> hn(Fn);
                 if (child.slot) DSM_HIP(hipMemcpyAsync(hs.data(), child.slot, (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
-                else {  // the last symbol of the node's path word
+                else if (child.srec) {  // stream mode: the symbol sits in the record
+                    std::vector<uint4> hr(Fn);
+                    DSM_HIP(hipMemcpyAsync(hr.data(), child.srec, (size_t)Fn * sizeof(uint4), hipMemcpyDeviceToHost, st));
+                    DSM_HIP(hipStreamSynchronize(st));
+                    for (u32 v = 0; v < Fn; ++v) hs[v] = hr[v].y & 3u;
+                } else {  // the last symbol of the node's path word
                     std::vector<uint2> hp(Fn);
                     DSM_HIP(hipMemcpyAsync(hp.data(), child.pw, (size_t)Fn * sizeof(uint2), hipMemcpyDeviceToHost, st));
                     DSM_HIP(hipStreamSynchronize(st));
@@ -3332,7 +3471,7 @@ class Engine {
         return 0;
     }
 
-    // ---- stream: byte offsets of every token from subtree sizes ------------------------------------
+    // ---- stream: chunks of the depth-first serialisation, one per leaf (see the kernels) ------------------------------
     int finish_stream(std::vector<LevelHost>& L, u32 nlev, dsm_byte_sink sink, void* ctx) {
         if (nlev < 2) {  // nothing below the root: the client sends only its handshake
             sout.submit(0, 0, stream_tag, 0, 0, stream_last);
@@ -3340,50 +3479,91 @@ class Engine {
         }
         // one connection per prefix: reported starts at 0 (EnumerateQuery.h:19-21); a sub-run of a split prefix continues the count
         const u64 rbase = stream_rbase;
+        const u32 ntop = nlev - 1 < 6 ? nlev - 1 : 6;  // levels whose nodes send an 'R' token
+        u32 maxn = 1;
         for (u32 l = 0; l < nlev; ++l) {
-            ARENA_GET(L[l].sz, u64, L[l].n);
-            ARENA_GET(L[l].pre, u64, L[l].n);
-            ARENA_GET(L[l].own, u64, L[l].n);
-            ARENA_GET(L[l].bytes, u64, L[l].n);
-            ARENA_GET(L[l].off, u64, L[l].n);
+            ARENA_GET(L[l].lf, u32, L[l].n);
+            maxn = L[l].n > maxn ? L[l].n : maxn;
         }
-        for (u32 l = nlev; l-- > 0;)  // subtree node counts
-            hipLaunchKernelGGL((up_kernel<u64, u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, (const u32*)nullptr, L[l].kids(),
-                               l + 1 < nlev ? L[l + 1].sz : nullptr, L[l].sz);
-        {  // pre-order numbers: pre(child_k) = pre(v) + 1 + sum sz(earlier siblings); root pre = -1
-            u64 m1 = ~0ull;
-            DSM_HIP(hipMemcpyAsync(L[0].pre, &m1, 8, hipMemcpyHostToDevice, st));
-            for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].pre, (u64)1, L[l].kids(), L[l + 1].sz, L[l + 1].pre);
+        for (u32 l = 1; l <= ntop; ++l) {
+            ARENA_GET(L[l].top_rank, u32, L[l].n);
+            ARENA_GET(L[l].top_lf, u32, L[l].n);
+            ARENA_GET(L[l].rval, u64, L[l].n);
         }
-        for (u32 l = 1; l < nlev; ++l)
-            hipLaunchKernelGGL((stream_own_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, (const P*)L[l].freq, L[l].pre, L[l].sz, L[l].own);
-        DSM_HIP(hipMemsetAsync(L[0].own, 0, 8, st));
-        for (u32 l = nlev; l-- > 0;)  // subtree bytes
-            hipLaunchKernelGGL((up_kernel<u64, u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].own, L[l].kids(),
-                               l + 1 < nlev ? L[l + 1].bytes : nullptr, L[l].bytes);
-        {  // byte offsets: off(child_k) = off(v) + 2 + sum bytes(earlier siblings); root off = -2
-            u64 m2 = ~0ull - 1;
-            DSM_HIP(hipMemcpyAsync(L[0].off, &m2, 8, hipMemcpyHostToDevice, st));
-            for (u32 l = 0; l + 1 < nlev; ++l)
-                hipLaunchKernelGGL((down_kernel<u64>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].off, (u64)2, L[l].kids(), L[l + 1].bytes, L[l + 1].off);
-        }
-        u64 total = 0;
-        DSM_HIP(hipMemcpyAsync(&total, L[0].bytes, 8, hipMemcpyDeviceToHost, st));
-        // a sub-run of a split prefix leaves out the closing tokens of the first stream_tail_levels nodes of its enforced path
-        std::vector<u64> tail_own(stream_tail_levels < nlev ? stream_tail_levels : nlev - 1, 0);
-        for (size_t l = 0; l < tail_own.size(); ++l) DSM_HIP(hipMemcpyAsync(&tail_own[l], L[l + 1].own, 8, hipMemcpyDeviceToHost, st));
+        for (u32 l = nlev; l-- > 0;)  // leaves per subtree
+            hipLaunchKernelGGL(stream_leaves_kernel, grid_npt(L[l].n), dim3(256), 0, st, L[l].n, L[l].kids(), l + 1 < nlev ? L[l + 1].lf : (const u32*)nullptr,
+                               L[l].lf);
+        u32 nleaf = 0;
+        DSM_HIP(hipMemcpyAsync(&nleaf, L[0].lf, sizeof(u32), hipMemcpyDeviceToHost, st));
         DSM_HIP(hipStreamSynchronize(st));
+        if (nleaf == 0) return fail(DSM_E_HIP, "wire stream: no leaves");
+        u64 *leaf_id, *cumk, *chunk_off, *stmp;
+        u32 *chunk, *kop, *trip[2][3];
+        ARENA_GET(leaf_id, u64, nleaf);
+        ARENA_GET(chunk, u32, nleaf);
+        ARENA_GET(kop, u32, nleaf);
+        ARENA_GET(cumk, u64, (size_t)nleaf + 1);
+        ARENA_GET(chunk_off, u64, (size_t)nleaf + 1);
+        ARENA_GET(stmp, u64, scan_tmp_elems(nleaf) + 8);
+        for (int k = 0; k < 2; ++k)
+            for (int q = 0; q < 3; ++q) ARENA_GET(trip[k][q], u32, maxn);
+        for (int q = 0; q < 3; ++q) DSM_HIP(hipMemsetAsync(trip[0][q], 0, sizeof(u32), st));  // the root: first leaf 0, nothing inherited
+        for (u32 l = 0; l < nlev; ++l) {  // top-down: leaf ranks and run sizes; the leaves' chunks
+            StreamDown a;
+            memset(&a, 0, sizeof a);
+            a.F = L[l].n; a.level = l;
+            a.rank = trip[l & 1][0]; a.kin = trip[l & 1][1]; a.cin = trip[l & 1][2];
+            a.rank_n = trip[(l + 1) & 1][0]; a.kin_n = trip[(l + 1) & 1][1]; a.cin_n = trip[(l + 1) & 1][2];
+            a.srec = l >= 1 ? L[l].srec : nullptr;
+            a.child_lf = l + 1 < nlev ? L[l + 1].lf : nullptr;
+            a.kids = L[l].kids();
+            a.leaf_id = leaf_id; a.chunk = chunk; a.kop = kop;
+            a.top_rank = (l >= 1 && l <= ntop) ? L[l].top_rank : nullptr;
+            a.top_lf = (l >= 1 && l <= ntop) ? L[l].top_lf : nullptr;
+            a.lf = L[l].lf;
+            hipLaunchKernelGGL(stream_down_kernel, dim3((L[l].n + TILE - 1) / TILE), dim3(256), 0, st, a);
+        }
+        // nodes opened before each chunk -> the values of the 'R' tokens, whose bytes join the chunk of the node's last leaf
+        exclusive_scan<u32, u64>(kop, cumk, nleaf, stmp, (u64*)nullptr, st);
+        for (u32 l = 1; l <= ntop; ++l)
+            hipLaunchKernelGGL(stream_rtok_kernel, grid_for(L[l].n), dim3(256), 0, st, L[l].n, rbase, L[l].top_rank, L[l].top_lf, cumk, kop, nleaf, L[l].rval,
+                               chunk);
+        exclusive_scan<u32, u64>(chunk, chunk_off, nleaf, stmp, d_totals64 + 2, st);
+        u64 total = 0;
+        DSM_HIP(hipMemcpyAsync(&total, d_totals64 + 2, 8, hipMemcpyDeviceToHost, st));
+        // a sub-run of a split prefix leaves out the closing tokens of the first stream_tail_levels nodes of its enforced path:
+        // node 0 of the levels 1, 2, ... (one node per level there)
+        const size_t ntail = stream_tail_levels < nlev ? stream_tail_levels : nlev - 1;
+        std::vector<uint4> tail_rec(ntail);
+        std::vector<u64> tail_rval(ntail, 0);
+        for (size_t l = 0; l < ntail; ++l) {
+            DSM_HIP(hipMemcpyAsync(&tail_rec[l], L[l + 1].srec, sizeof(uint4), hipMemcpyDeviceToHost, st));
+            if (l + 1 <= ntop) DSM_HIP(hipMemcpyAsync(&tail_rval[l], L[l + 1].rval, 8, hipMemcpyDeviceToHost, st));
+        }
+        DSM_HIP(hipStreamSynchronize(st));
+        auto vlen = [](u64 u) { u32 n = 1; if (u >= 128) { u32 bits = 0; for (u64 t = u; t; t >>= 1) ++bits; n = 1 + (bits + 7) / 8; } return (u64)n; };
         u64 tail_bytes = 0;
-        for (u64 o : tail_own) tail_bytes += o - 2;  // (own counts the two opening bytes as well)
+        for (size_t l = 0; l < ntail; ++l) {
+            const u64 fw = ((u64)tail_rec[l].w << 32) | tail_rec[l].z;
+            tail_bytes += vlen(fw & ((1ull << 61) - 1)) + 2 + (l + 1 <= ntop ? 1 + vlen(tail_rval[l]) : 0);
+        }
         if (stream_head_skip + tail_bytes > total) return fail(DSM_E_HIP, "split stream: slice larger than the stream");
         int k = 0;
         if (int rc = sout.acquire(total, device, &k)) return rc;  // (waits for the prefix before the previous one to have left the card)
         u8* d_out = sout.buf[k];
-        for (u32 l = 1; l < nlev; ++l)
-            hipLaunchKernelGGL((stream_write_kernel<P>), grid_for(L[l].n), dim3(256), 0, st, L[l].n, l, rbase, L[l].slot, (const P*)L[l].freq, L[l].left, L[l].pre,
-                               L[l].sz, L[l].off, L[l].bytes, L[l].own, d_out);
+        // the per-level tables of the writer
+        std::vector<const uint4*> h_rec(nlev, nullptr);
+        std::vector<const u64*> h_rval(nlev, nullptr);
+        for (u32 l = 1; l < nlev; ++l) { h_rec[l] = L[l].srec; h_rval[l] = L[l].rval; }
+        const uint4** d_rec;
+        const u64** d_rv;
+        ARENA_GET(d_rec, const uint4*, nlev);
+        ARENA_GET(d_rv, const u64*, nlev);
+        DSM_HIP(hipMemcpyAsync(d_rec, h_rec.data(), nlev * sizeof(void*), hipMemcpyHostToDevice, st));
+        DSM_HIP(hipMemcpyAsync(d_rv, h_rval.data(), nlev * sizeof(void*), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(stream_chunk_kernel, grid_for(nleaf), dim3(256), 0, st, nleaf, nlev, d_rec, d_rv, leaf_id, chunk_off, kop, d_out);
         DSM_HIP(hipGetLastError());
+        DSM_HIP(hipStreamSynchronize(st));  // (the tables on the host stack above must outlive their copies)
         DSM_HIP(hipEventRecord(sout.ready[k], st));
         sout.submit(k, total, stream_tag, stream_head_skip, total - stream_head_skip - tail_bytes, stream_last);
         return 0;

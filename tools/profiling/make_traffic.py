@@ -16,8 +16,10 @@ def trace(path, steps, warm):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows]
     passes = steps + warm
+    if len(sys.argv) > 5:
+        passes += int(sys.argv[5])  # further untimed passes of the profiled command (they come last)
     per = len(dur) // passes
-    timed = dur[per * warm:]
+    timed = dur[per * warm: per * (warm + steps)]
     noop = [d for d in timed if d < 2500]          # a launch that only compares two words: 1.3 us
     real = [d for d in timed if d >= 2500]
     out = {"expand_launches_per_pass_total": per, "noop_launches_per_pass": len(noop) / steps, "real_launches_per_pass": len(real) / steps,
@@ -42,8 +44,11 @@ def traffic(pmc_path, bench_path, trace_path):
     tr = json.loads(open(trace_path).read())
     launches = bench["roofline"]["launches"] // bench["steps"]
     nodes = bench["detail"]["rank0_nodes_per_step"]
-    fetch = agg["FETCH_SIZE"][0] * 1024.0   # KiB
-    write = agg["WRITE_SIZE"][0] * 1024.0
+    # passes the profiled command ran: launches the counters saw / launches of a pass (the real ones plus the dozen queued ahead
+    # that returned at once); bench.py --steps 1 --warmup 0 is one pass (round 3's run had a second, untimed one: the text-format pass)
+    passes = max(1, round(agg["FETCH_SIZE"][1] / (launches + 12.0)))
+    fetch = agg["FETCH_SIZE"][0] * 1024.0 / passes   # KiB
+    write = agg["WRITE_SIZE"][0] * 1024.0 / passes
     known = 20.0 * nodes                    # 16-byte compact record + 4-byte handle per node read, coalesced
     per_step = fetch + 0.5 * known + write
     hit, miss = agg.get("TCC_HIT_sum", [0, 0])[0], agg.get("TCC_MISS_sum", [0, 0])[0]
@@ -57,7 +62,7 @@ def traffic(pmc_path, bench_path, trace_path):
            "rocprof_avg_launch_ms": tr["rocprof_avg_launch_ms"], "rocprof_expand_ms_per_step": tr["rocprof_expand_ms_per_step"],
            "bench_avg_launch_ms_same_box": bench["roofline"]["avg_launch_ms"],
            "bench_expand_ms_per_step_same_box": bench["detail"]["expand_ms_per_step"],
-           "pmc_launches_seen": agg["FETCH_SIZE"][1],
+           "pmc_launches_seen": agg["FETCH_SIZE"][1], "pmc_passes": passes,
            "sq": {k: v[0] for k, v in agg.items() if k.startswith("SQ_")},
            "source": "tools/profiling/r03_final.sh on one box: bench.py --steps 3 --warmup 1 (JSON line and kernel trace), then one "
                      "rocprofv3 --pmc pass per counter group of bench.py --steps 1 --warmup 0 --no-cpu --no-extras"}
