@@ -870,7 +870,7 @@ __device__ __forceinline__ uint2 child_path_word(const uint2 parent, u32 u, u32 
 
 struct AdvanceOut {
     u32* slot;        // retained: 4*parent + sym of every new node (null: nobody reads the links -- mining without derived handles)
-    uint4* srec;      // stream mode: the new nodes' records (parent and symbol / first / last flags are written here, see keep_kernel)
+    uint2* sa;        // stream mode: per new node its parent index and symbol / first / last flags (keep_kernel completes the record)
     uint2* pw;        // retained path words of the new nodes (null: stream mode); pw_after_slot: they follow the slot array, whose length
     const uint2* parent_pw;  // (the new level's width) only the device knows when this sweep runs -- *width, or the single tile's total
     const u32* width;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void advance_down_kernel(Xchg x, AdvanceOut o)
             if (((pres >> c) & 1u) && vj[c] < o.cap) {  // a level wider than its arrays is reported through the total, not written
                 if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
                 if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
-                if (o.srec) reinterpret_cast<uint2*>(o.srec + vj[c])[0] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
+                if (o.sa) o.sa[vj[c]] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
                 if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
             }
         }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
         if (((pres >> c) & 1u) && vj[c] < o.cap) {
             if (o.slot) o.slot[vj[c]] = 4u * u + (u32)c;
             if (pw) pw[vj[c]] = child_path_word(mypw, u, o.plevel, (u32)c);
-            if (o.srec) reinterpret_cast<uint2*>(o.srec + vj[c])[0] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
+            if (o.sa) o.sa[vj[c]] = make_uint2(u, (u32)c | ((pres & ((1u << c) - 1u)) ? 0u : SREC_FIRST) | ((pres >> (c + 1)) ? 0u : SREC_LAST));
             if (!o.single) o.nT[vj[c]] = (u16)nT4[c];
         }
     }
@@ -1462,14 +1462,16 @@ __global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, c
 }
 
 // stream mode (one sample): a level retains one 16-byte record per node for the wire stream:
-//   .x parent index, .y symbol | first-child << 2 | last-child << 3 (written by the advance sweep of the parent's level),
-//   .z/.w frequency | left-char code << 61 (written here, when the node's own level has been expanded)
+//   .x parent index, .y symbol | first-child << 2 | last-child << 3 (from the advance sweep of the parent's level, which leaves
+//   them in a dense 8-byte array of its own: both kernels then write whole lines),
+//   .z/.w frequency | left-char code << 61 (known when the node's own level has been expanded: here)
 template <typename P>
-__global__ void keep_kernel(u32 F, Xchg x, uint4* __restrict__ srec) {
+__global__ void keep_kernel(u32 F, Xchg x, const uint2* __restrict__ sa, uint4* __restrict__ srec) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
+    const uint2 a = sa[v];
     const u64 w = (u64)x_freq<P>(x, 0, v) | ((u64)(x_pl<P>(x, 0, v) >> 4) << 61);
-    reinterpret_cast<uint2*>(srec + v)[1] = make_uint2((u32)w, (u32)(w >> 32));
+    srec[v] = make_uint4(a.x, a.y, (u32)w, (u32)(w >> 32));
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
@@ -1816,14 +1818,14 @@ __global__ void stream_rtok_kernel(u32 F, u64 rbase, const u32* __restrict__ top
 
 // one thread per leaf, in trie order: the chunk, front to back
 constexpr u32 STREAM_LDS_LEVELS = 1024;
-__global__ __launch_bounds__(256) void stream_chunk_kernel(u32 nleaf, u32 nlev, const uint4* const* __restrict__ srec_tab, const u64* const* __restrict__ rval_tab,
+__global__ __launch_bounds__(256) void stream_chunk_kernel(u32 rank0, u32 nleaf, u32 nlev, const uint4* const* __restrict__ srec_tab, const u64* const* __restrict__ rval_tab,
                                                            const u64* __restrict__ leaf_id, const u64* __restrict__ chunk_off, const u32* __restrict__ kop,
                                                            u8* __restrict__ out) {
     __shared__ const uint4* s_rec[STREAM_LDS_LEVELS];
     const u32 nl = nlev < STREAM_LDS_LEVELS ? nlev : STREAM_LDS_LEVELS;
     for (u32 q = threadIdx.x; q < nl; q += blockDim.x) s_rec[q] = srec_tab[q];
     __syncthreads();
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 r = rank0 + blockIdx.x * blockDim.x + threadIdx.x;  // (leaves rank0 .. nleaf - 1: a slice of the stream)
     if (r >= nleaf) return;
     const u64 id = leaf_id[r];
     u32 l = (u32)(id >> 32), v = (u32)id;
@@ -2156,7 +2158,11 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
 // Host worker of the wire-stream path: the bytes of prefix k cross PCIe and reach the sink while the GPU already works on prefix
 // k+1.  Two device buffers alternate between the prefixes; pieces go through two pinned staging buffers.
 struct StreamOut {
-    struct Job { int k; u64 total; int tag; u64 off; u64 len; bool last; };  // bytes [off, off + len) of the buffer; last: the prefix ends here
+    // bytes [off, off + len) of the buffer, written when `ev` has happened; last: the prefix ends here; release: the buffer is free
+    // after this job (a prefix's stream leaves in slices: the first ones cross the bus while the last ones are still being written)
+    struct Job { int k; u64 total; int tag; u64 off; u64 len; bool last; hipEvent_t ev; bool release; };
+    static constexpr int MAX_SLICES = 8;
+    hipEvent_t sev[2][MAX_SLICES] = {{nullptr}, {nullptr}};
     u8* buf[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     bool busy[2] = {false, false};
@@ -2180,7 +2186,7 @@ struct StreamOut {
     int deliver(const Job& j) {
         (void)hipSetDevice(device);
         if (j.total) {
-            if (hipStreamWaitEvent(copy_stream, ready[j.k], 0) != hipSuccess) return 2;
+            if (hipStreamWaitEvent(copy_stream, j.ev ? j.ev : ready[j.k], 0) != hipSuccess) return 2;
             const u8* src = buf[j.k] + j.off;
             const u64 np = (j.len + PIECE - 1) / PIECE;
             auto bytes = [&](u64 i) { return (size_t)((j.len - i * PIECE) < PIECE ? (j.len - i * PIECE) : PIECE); };
@@ -2212,7 +2218,7 @@ struct StreamOut {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc && !err) err = rc;
                 if (!rc) delivered += j.len;
-                if (j.total) busy[j.k] = false;
+                if (j.total && j.release) busy[j.k] = false;
                 --inflight;
             }
             cv.notify_all();
@@ -2241,15 +2247,19 @@ struct StreamOut {
         *k_out = k;
         return 0;
     }
-    void submit(int k, u64 total, int tag, u64 off, u64 len, bool last) {  // total == 0: nothing below the root, only the end-of-prefix call
+    void submit(int k, u64 total, int tag, u64 off, u64 len, bool last, hipEvent_t ev = nullptr, bool release = true) {  // total == 0: nothing below the root, only the end-of-prefix call
         {
             std::lock_guard<std::mutex> lk(mu);
             if (!started) { started = true; th = std::thread([this] { loop(); }); }
             if (total) { busy[k] = true; next = k ^ 1; }
             ++inflight;
-            q.push_back(Job{k, total, tag, off, len, last});
+            q.push_back(Job{k, total, tag, off, len, last, ev, release});
         }
         cv.notify_all();
+    }
+    hipEvent_t slice_event(int k, int j) {
+        if (!sev[k][j] && hipEventCreateWithFlags(&sev[k][j], hipEventDisableTiming) != hipSuccess) return nullptr;
+        return sev[k][j];
     }
     int drain() {
         std::unique_lock<std::mutex> lk(mu);
@@ -2268,6 +2278,7 @@ struct StreamOut {
         for (int k = 0; k < 2; ++k) {
             if (buf[k]) (void)hipFree(buf[k]);
             if (ready[k]) (void)hipEventDestroy(ready[k]);
+            for (auto e : sev[k]) if (e) (void)hipEventDestroy(e);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
@@ -2409,6 +2420,7 @@ class Engine {
     int owner = 0;
     u8* bc_buf = nullptr;     // owner mode: the broadcast message, 16-byte header + 32 bytes per 64 parents
     u32* lite_slot[2] = {nullptr, nullptr};  // owner mode, clients: links of the levels (ping-pong)
+    uint2* sa[2] = {nullptr, nullptr};       // stream mode: parent / symbol / flags of the level being built (ping-pong, see keep_kernel)
     u32 pub_seq = 0;          // sequence number of the last publish kernel
     u32 Seg = 0;              // handles per symbol segment of a record buffer: Fcap rounded up to whole tiles
     u32 Rcap = 0;             // handles of a record buffer = 4 * Seg
@@ -2616,6 +2628,8 @@ class Engine {
         if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
         if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
+        if (stream_mode)
+            for (int k = 0; k < 2; ++k) if (int rc = dalloc(sa[k], (size_t)Fcap + 64)) return rc;
         if (owner_mode) {
             if (int rc = dalloc(bc_buf, 16 + 32 * nwave + 64)) return rc;
             for (int k = 0; k < 2; ++k) if (int rc = dalloc(lite_slot[k], (size_t)Fcap + 64)) return rc;
@@ -3043,8 +3057,10 @@ class Engine {
             LevelHost child;
             // the arena hands out memory past `off`; the new level's arrays are claimed after Fn is known, so
             // the down-sweep writes into a provisional window that is then committed
-            if (stream_mode && depth >= 1)  // this level's own frequencies / left chars complete its records for the wire stream
-                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, me.srec);
+            if (stream_mode && depth >= 1) {  // this level's own frequencies / left chars complete its records for the wire stream
+                ARENA_GET(me.srec, uint4, F);
+                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, sa[cur], me.srec);
+            }
             const bool emit_here = !stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi;
             bool filtered = false;
             if (emit_here) {
@@ -3057,16 +3073,16 @@ class Engine {
             // What a level retains per node: the links (4 * parent + symbol) where something reads them -- the wire stream, handles
             // derived inside the LF-step kernel -- and the path words when tuples are mined.  With both, the words follow the links,
             // whose length only the device knows when the sweep runs: the window is sized for the widest level possible here.
-            const bool keep_slot = self_mode, keep_pw = !stream_mode, keep_srec = stream_mode;  // (stream mode: one 16-byte record per node)
+            const bool keep_slot = self_mode, keep_pw = !stream_mode;  // (stream mode: records, completed at the node's own level)
             const size_t wcap = (size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap;
-            u8* window = arena.get<u8>(wcap * ((keep_slot ? 4 : 0) + (keep_pw ? 8 : 0) + (keep_srec ? 16 : 0)) + 512);
+            u8* window = arena.get<u8>(wcap * ((keep_slot ? 4 : 0) + (keep_pw ? 8 : 0)) + 512);
             if (!window) return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
             u32* new_slot2 = keep_slot ? reinterpret_cast<u32*>(window) : nullptr;
             const u32 nbp = (F + TILE - 1) / TILE;  // tiles of this level
             AdvanceOut ao;
             memset(&ao, 0, sizeof ao);
             ao.slot = new_slot2; ao.nT = nT[nxt]; ao.samechild = samechild;
-            if (keep_srec) ao.srec = reinterpret_cast<uint4*>(window);
+            if (stream_mode) ao.sa = sa[nxt];
             if (keep_pw) {
                 ao.pw = reinterpret_cast<uint2*>(window);  // (behind the links: the kernels place it, see pw_after_slot)
                 ao.pw_after_slot = keep_slot ? 1u : 0u;
@@ -3163,7 +3179,6 @@ class Engine {
             if (Fn) {
                 if (keep_slot) child.slot = arena.get<u32>(Fn);   // same address as new_slot2
                 if (keep_pw) child.pw = arena.get<uint2>(Fn);     // the window's start, or right behind the links (256-byte granules, as the kernels assume)
-                if (keep_srec) child.srec = arena.get<uint4>(Fn);
                 if (int rc = alloc_kids(child)) return rc;
                 if (spec_hit) {
                     stats.expand_slots += Fn;
@@ -3195,9 +3210,9 @@ class Engine {
                 std::vector<u32> hs(Fn);
                 std::vector<u16> hn(Fn);
                 if (child.slot) DSM_HIP(hipMemcpyAsync(hs.data(), child.slot, (size_t)Fn * sizeof(u32), hipMemcpyDeviceToHost, st));
-                else if (child.srec) {  // stream mode: the symbol sits in the record
-                    std::vector<uint4> hr(Fn);
-                    DSM_HIP(hipMemcpyAsync(hr.data(), child.srec, (size_t)Fn * sizeof(uint4), hipMemcpyDeviceToHost, st));
+                else if (stream_mode) {  // the symbol sits in the second word of the sweep's (parent, flags) pair
+                    std::vector<uint2> hr(Fn);
+                    DSM_HIP(hipMemcpyAsync(hr.data(), sa[nxt], (size_t)Fn * sizeof(uint2), hipMemcpyDeviceToHost, st));
                     DSM_HIP(hipStreamSynchronize(st));
                     for (u32 v = 0; v < Fn; ++v) hs[v] = hr[v].y & 3u;
                 } else {  // the last symbol of the node's path word
@@ -3531,6 +3546,14 @@ class Engine {
         exclusive_scan<u32, u64>(chunk, chunk_off, nleaf, stmp, d_totals64 + 2, st);
         u64 total = 0;
         DSM_HIP(hipMemcpyAsync(&total, d_totals64 + 2, 8, hipMemcpyDeviceToHost, st));
+        // The stream leaves the card in slices of consecutive leaves: slice j crosses the bus while the later ones are still being
+        // written, so the part of a pass that nothing overlaps is the last slice of its last prefix, not a whole prefix.
+        const int nslice = nleaf >= (1u << 22) ? 4 : 1;
+        u32 srank[StreamOut::MAX_SLICES + 1];
+        u64 sbyte[StreamOut::MAX_SLICES + 1];
+        for (int j = 0; j <= nslice; ++j) srank[j] = (u32)((u64)nleaf * j / nslice);
+        sbyte[0] = 0;
+        for (int j = 1; j < nslice; ++j) DSM_HIP(hipMemcpyAsync(&sbyte[j], chunk_off + srank[j], 8, hipMemcpyDeviceToHost, st));
         // a sub-run of a split prefix leaves out the closing tokens of the first stream_tail_levels nodes of its enforced path:
         // node 0 of the levels 1, 2, ... (one node per level there)
         const size_t ntail = stream_tail_levels < nlev ? stream_tail_levels : nlev - 1;
@@ -3561,11 +3584,21 @@ class Engine {
         ARENA_GET(d_rv, const u64*, nlev);
         DSM_HIP(hipMemcpyAsync(d_rec, h_rec.data(), nlev * sizeof(void*), hipMemcpyHostToDevice, st));
         DSM_HIP(hipMemcpyAsync(d_rv, h_rval.data(), nlev * sizeof(void*), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(stream_chunk_kernel, grid_for(nleaf), dim3(256), 0, st, nleaf, nlev, d_rec, d_rv, leaf_id, chunk_off, kop, d_out);
-        DSM_HIP(hipGetLastError());
+        sbyte[nslice] = total;
+        const u64 lo = stream_head_skip, hi = total - tail_bytes;  // what of the buffer is sent
         DSM_HIP(hipStreamSynchronize(st));  // (the tables on the host stack above must outlive their copies)
-        DSM_HIP(hipEventRecord(sout.ready[k], st));
-        sout.submit(k, total, stream_tag, stream_head_skip, total - stream_head_skip - tail_bytes, stream_last);
+        for (int j = 0; j < nslice; ++j) {
+            if (srank[j + 1] > srank[j])
+                hipLaunchKernelGGL(stream_chunk_kernel, grid_for(srank[j + 1] - srank[j]), dim3(256), 0, st, srank[j], srank[j + 1], nlev, d_rec, d_rv, leaf_id,
+                                   chunk_off, kop, d_out);
+            hipEvent_t ev = sout.slice_event(k, j);
+            if (!ev) return fail(DSM_E_HIP, "hipEventCreate failed");
+            DSM_HIP(hipEventRecord(ev, st));
+            const u64 a = sbyte[j] > lo ? sbyte[j] : lo, b = sbyte[j + 1] < hi ? sbyte[j + 1] : hi;
+            const bool final_slice = j + 1 == nslice;
+            sout.submit(k, total, stream_tag, a, b > a ? b - a : 0, stream_last && final_slice, ev, final_slice);
+        }
+        DSM_HIP(hipGetLastError());
         return 0;
     }
     StreamOut sout;
