@@ -1466,12 +1466,16 @@ __global__ __launch_bounds__(256) void cand_store_kernel(FilterArgs a, Xchg x, c
 //   them in a dense 8-byte array of its own: both kernels then write whole lines),
 //   .z/.w frequency | left-char code << 61 (known when the node's own level has been expanded: here)
 template <typename P>
-__global__ void keep_kernel(u32 F, Xchg x, const uint2* __restrict__ sa, uint4* __restrict__ srec) {
+__global__ void keep_kernel(u32 F, Xchg x, const uint2* __restrict__ sa, uint4* __restrict__ srec, u8* __restrict__ clen) {
     u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= F) return;
     const uint2 a = sa[v];
-    const u64 w = (u64)x_freq<P>(x, 0, v) | ((u64)(x_pl<P>(x, 0, v) >> 4) << 61);
+    const u64 f = (u64)x_freq<P>(x, 0, v);
+    const u64 w = f | ((u64)(x_pl<P>(x, 0, v) >> 4) << 61);
     srec[v] = make_uint4(a.x, a.y, (u32)w, (u32)(w >> 32));
+    // bytes of the node's closing token without an 'R' part: varint(freq) left ')' (ClientSocket.h:20-39); the top-down sweep of
+    // the stream reads this byte instead of the record
+    clen[v] = (u8)((f < 128 ? 1u : 1u + (u32)((64 - __clzll((long long)f) + 7) >> 3)) + 2u);
 }
 
 // ---- subtree aggregates over the retained levels ------------------------------------------------
@@ -1742,7 +1746,7 @@ struct StreamDown {
     u32* rank_n;          // next level
     u32* kin_n;
     u32* cin_n;
-    const uint4* srec;    // this level's records (null at level 0: the root is not a node of the stream)
+    const u8* clen;       // this level's closing-token sizes (null at level 0: the root is not a node of the stream)
     const u32* child_lf;  // leaves per subtree of the next level (null: this is the last level)
     Kids kids;
     u64* leaf_id;         // per leaf rank: level << 32 | node
@@ -1767,8 +1771,8 @@ __global__ __launch_bounds__(256) void stream_down_kernel(StreamDown a) {
         m = (u32)((kw.p[0] >> lane) & 1) | ((u32)((kw.p[1] >> lane) & 1) << 1) | ((u32)((kw.p[2] >> lane) & 1) << 2) | ((u32)((kw.p[3] >> lane) & 1) << 3);
     }
     const u32 rank = a.rank[vc], kin = a.kin[vc], cin = a.cin[vc];
-    u64 fw = 0;
-    if (a.srec) fw = srec_word(a.srec[vc]);
+    u32 mylen = 0;
+    if (a.clen) mylen = a.clen[vc];
     u32 g[3] = {0, 0, 0};
     if (a.child_lf) {
 #pragma unroll
@@ -1779,7 +1783,7 @@ __global__ __launch_bounds__(256) void stream_down_kernel(StreamDown a) {
     }
     if (!in) return;
     const u32 kopen = a.level >= 1 ? kin + 1 : 0u;                                                   // open run down to and including this node
-    const u32 cb = a.level >= 1 ? cin + varint_len(fw & SREC_FREQ_MASK) + 2u : 0u;                   // close run: varint(freq) left ')'
+    const u32 cb = a.level >= 1 ? cin + mylen : 0u;                                                  // close run: varint(freq) left ')'
     if (a.top_rank) { a.top_rank[v] = rank; a.top_lf[v] = a.lf[v]; }
     if (!m) {  // a leaf: its chunk
         if (a.level >= 1) {
@@ -1900,6 +1904,7 @@ struct LevelHost {
     u32* sub = nullptr;
     // stream
     uint4* srec = nullptr;      // per node: parent, symbol and first / last flags, frequency and left char (keep_kernel)
+    u8* clen = nullptr;         // bytes of the node's closing token (without an 'R' part)
     u32* lf = nullptr;          // leaves in the subtree
     u32* top_rank = nullptr;    // levels 1..6: rank of the first leaf, leaves, value of the 'R' token
     u32* top_lf = nullptr;
@@ -3059,7 +3064,8 @@ class Engine {
             // the down-sweep writes into a provisional window that is then committed
             if (stream_mode && depth >= 1) {  // this level's own frequencies / left chars complete its records for the wire stream
                 ARENA_GET(me.srec, uint4, F);
-                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, sa[cur], me.srec);
+                ARENA_GET(me.clen, u8, F);
+                hipLaunchKernelGGL((keep_kernel<P>), grid_for(F), dim3(256), 0, st, F, x, sa[cur], me.srec, me.clen);
             }
             const bool emit_here = !stream_mode && emitting && depth >= 1 && depth >= emit_lo && depth <= emit_hi;
             bool filtered = false;
@@ -3529,7 +3535,7 @@ class Engine {
             a.F = L[l].n; a.level = l;
             a.rank = trip[l & 1][0]; a.kin = trip[l & 1][1]; a.cin = trip[l & 1][2];
             a.rank_n = trip[(l + 1) & 1][0]; a.kin_n = trip[(l + 1) & 1][1]; a.cin_n = trip[(l + 1) & 1][2];
-            a.srec = l >= 1 ? L[l].srec : nullptr;
+            a.clen = l >= 1 ? L[l].clen : nullptr;
             a.child_lf = l + 1 < nlev ? L[l + 1].lf : nullptr;
             a.kids = L[l].kids();
             a.leaf_id = leaf_id; a.chunk = chunk; a.kop = kop;
