@@ -2,12 +2,16 @@
 // tuples out (what N metaenumerate clients + one metaserver per prefix produce, metaserver.cpp:467-485).
 // Sample ids follow the order of the index files (the server's names order).
 //   dsm_node -E emax [-e emin] [-P pmin] [--pmax N] [-m mindepth] [-f fmin] [-M maxdepth]
-//            [--device D | --devices D0,D1,...] [--out-prefix path.] -p PREFIX[,PREFIX...] a.fmi b.fmi ...
+//            [--device D | --devices D0,D1,... [--exchange allgather|owner]] [--out-prefix path.] -p PREFIX[,PREFIX...] a.fmi b.fmi ...
 // One device: one miner holds every index.  Several devices (--devices): the reference's fan-out -- one metaenumerate per
 // sample (wrapper-SLURM/example-client.sh:27-30), one socket and one server per prefix (metaenumerate.cpp:268-309) -- becomes
 // one thread + HIP stream per GPU inside this process, the samples dealt out in blocks (sample k lives on device k / (d / G)),
 // and ONE ncclAllGather (RCCL over xGMI) per frontier level, issued on the engine's stream from the library's exchange
 // callback.  Prefix k is filtered, ordered and emitted by device k mod G only; the outputs are written in prefix order.
+// --exchange owner: the reference's own partition -- prefix k is merged by device k mod G ALONE (one metaserver per prefix,
+// wrapper-SLURM/example-server.sh:27-41); the other devices send it their columns and get the union's child masks back
+// (dsm_params.owner_mode).  One lane per owner: G x G threads, lane j of every device works on the prefixes j, j + G, ..., so every
+// device is the server of one lane and a client in the others; the lanes' collectives are ordered by a gate per device.
 // With --out-prefix every prefix goes to <out-prefix><PREFIX>.txt (server-wrapper.sh:35 naming), else to stdout.
 #include <getopt.h>
 #include <unistd.h>
@@ -192,20 +196,159 @@ static int run_devices(const std::vector<int>& devs, const dsm_params& p, const 
     return 0;
 }
 
+// ---- several devices, owner mode ------------------------------------------------------------------------------------------
+struct LaneRank {
+    int rank = 0, lane = 0, world = 1, device = 0;
+    dsm_rccl* comm = nullptr;
+    dsm_rccl_gate* gate = nullptr;
+    hipStream_t stream = nullptr;
+    dsm_miner* miner = nullptr;
+    std::vector<std::string> prefixes;       // of this lane
+    std::vector<std::string>* out = nullptr; // one text per prefix of this lane (filled by the lane's owner)
+    dsm_stats st;
+};
+struct LaneSinkCtx { LaneRank* lr; };
+static int to_lane_text(void* ctx, const dsm_tuple_batch* b) {
+    LaneRank* r = (LaneRank*)ctx;
+    if (!b->ntuples) return 0;
+    const char* path = b->path_bytes + b->path_off[0];
+    const size_t plen = b->path_off[1] - b->path_off[0];
+    int best = -1;
+    for (size_t k = 0; k < r->prefixes.size(); ++k) {
+        const std::string& pre = r->prefixes[k];
+        if (pre.size() <= plen && memcmp(pre.data(), path, pre.size()) == 0) best = (int)k;
+    }
+    if (best < 0) return 1;
+    char* text = nullptr;
+    size_t len = 0;
+    if (dsm_format_batch(b, &text, &len)) return 1;
+    (*r->out)[best].append(text, len);
+    dsm_free(text);
+    return 0;
+}
+
+static int run_devices_owner(const std::vector<int>& devs, const dsm_params& p0, const std::vector<std::string>& prefixes,
+                             const std::vector<std::string>& files, const std::string& outprefix) {
+    const int G = (int)devs.size();
+    if (files.size() % G) { std::cerr << "dsm_node: the number of samples must be a multiple of the number of devices" << std::endl; return 1; }
+    const size_t nlocal = files.size() / G;
+    for (size_t a = 0; a < prefixes.size(); ++a)
+        for (size_t b = 0; b < prefixes.size(); ++b)
+            if (a != b && prefixes[b].compare(0, prefixes[a].size(), prefixes[a]) == 0) {
+                std::cerr << "dsm_node: --devices needs prefixes none of which starts with another (" << prefixes[a] << ", " << prefixes[b] << ")" << std::endl;
+                return 1;
+            }
+    std::vector<std::vector<uint8_t>> ids(G, std::vector<uint8_t>(DSM_RCCL_ID_BYTES));
+    for (int j = 0; j < G; ++j)
+        if (dsm_rccl_unique_id(ids[j].data())) { std::cerr << "dsm_node: " << dsm_last_error() << std::endl; return 1; }
+    std::vector<std::vector<LaneRank>> lr(G, std::vector<LaneRank>(G));       // [rank][lane]
+    std::vector<std::vector<std::string>> outs(G);                            // [lane][prefix of the lane]
+    for (int j = 0; j < G; ++j) {
+        std::vector<std::string> mine;
+        for (size_t k = j; k < prefixes.size(); k += G) mine.push_back(prefixes[k]);
+        outs[j].resize(mine.size());
+        for (int r = 0; r < G; ++r) {
+            lr[r][j].rank = r; lr[r][j].lane = j; lr[r][j].world = G; lr[r][j].device = devs[r];
+            lr[r][j].prefixes = mine; lr[r][j].out = &outs[j];
+        }
+    }
+    // per device: indexes, then lane by lane a communicator and a miner (creation runs collectives: every device thread goes
+    // through the lanes in the same order), then the gate; a failure before the lanes run ends the process
+    std::vector<std::vector<dsm_index*>> idx(G);
+    auto fatal = [](int device, const std::string& msg) {
+        std::cerr << "dsm_node: device " << device << ": " << msg << std::endl;
+        fflush(nullptr);
+        _exit(1);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; ++r)
+            th.emplace_back([&, r] {
+                if (hipSetDevice(devs[r]) != hipSuccess) fatal(devs[r], "hipSetDevice failed");
+                for (size_t k = 0; k < nlocal; ++k) {
+                    dsm_index* ix = nullptr;
+                    if (dsm_index_open(files[r * nlocal + k].c_str(), devs[r], &ix)) fatal(devs[r], files[r * nlocal + k] + ": " + dsm_last_error());
+                    idx[r].push_back(ix);
+                }
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                dsm_rccl_gate* gate = nullptr;
+                if (dsm_rccl_gate_create(G, &gate)) fatal(devs[r], dsm_last_error());
+                for (int j = 0; j < G; ++j) {
+                    LaneRank& L = lr[r][j];
+                    L.gate = gate;
+                    if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) fatal(devs[r], "hipStreamCreate failed");
+                    if (dsm_rccl_create(ids[j].data(), G, r, devs[r], &L.comm)) fatal(devs[r], dsm_last_error());
+                    dsm_params p = p0;
+                    p.world_size = (uint32_t)G; p.rank = (uint32_t)r;
+                    p.allgather = dsm_rccl_allgather; p.allgather_ctx = L.comm;
+                    p.owner_mode = 1; p.owner_rank = (uint32_t)j;
+                    p.gather = dsm_rccl_gather; p.bcast = dsm_rccl_bcast; p.owner_ctx = L.comm;
+                    p.stream = L.stream;
+                    p.arena_bytes = (uint64_t)(free_b * 0.7 / G);
+                    if (dsm_miner_create(idx[r].data(), (int)idx[r].size(), &p, 0, &L.miner)) fatal(devs[r], std::string("miner: ") + dsm_last_error());
+                }
+                for (int j = 0; j < G; ++j) (void)dsm_rccl_attach_gate(lr[r][j].comm, gate, j);
+            });
+        for (auto& t : th) t.join();
+    }
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; ++r)
+            for (int j = 0; j < G; ++j)
+                th.emplace_back([&, r, j] {
+                    LaneRank& L = lr[r][j];
+                    (void)hipSetDevice(L.device);
+                    dsm_rccl_gate_begin(L.gate, j);
+                    std::vector<const char*> pre;
+                    for (const std::string& s_ : L.prefixes) pre.push_back(s_.c_str());
+                    if (dsm_miner_mine_many(L.miner, pre.data(), (int)pre.size(), to_lane_text, &L, &L.st)) fatal(L.device, std::string("mine: ") + dsm_last_error());
+                    dsm_rccl_gate_retire(L.gate, j);
+                });
+        for (auto& t : th) t.join();
+    }
+    uint64_t nodes = 0, tuples = 0, sent = 0, recvd = 0;
+    for (int r = 0; r < G; ++r) {
+        for (int j = 0; j < G; ++j) {
+            LaneRank& L = lr[r][j];
+            nodes += L.st.reported; tuples += L.st.tuples; sent += L.st.exchange_bytes_sent; recvd += L.st.exchange_bytes_received;
+            dsm_miner_destroy(L.miner);
+            dsm_rccl_destroy(L.comm);
+            (void)hipStreamDestroy(L.stream);
+        }
+        dsm_rccl_gate_destroy(lr[r][0].gate);
+        for (auto* ix : idx[r]) dsm_index_close(ix);
+    }
+    for (size_t k = 0; k < prefixes.size(); ++k) {
+        FILE* f = g_out;
+        if (!outprefix.empty()) {
+            f = fopen((outprefix + prefixes[k] + ".txt").c_str(), "w");
+            if (!f) { std::cerr << "cannot open output for prefix " << prefixes[k] << std::endl; return 1; }
+        }
+        const std::string& text = outs[k % G][k / G];
+        fwrite(text.data(), 1, text.size(), f);
+        if (f != g_out) fclose(f);
+    }
+    fflush(g_out);
+    std::cerr << G << " device(s), owner mode: " << nodes << " nodes, " << tuples << " reported, " << sent << " bytes sent, " << recvd << " received" << std::endl;
+    return 0;
+}
+
 int main(int argc, char** argv) {
     fflush(stdout);
     g_out = fdopen(dup(1), "w");
     if (!g_out || dup2(2, 1) < 0) { std::cerr << "dsm_node: cannot set up the output" << std::endl; return 1; }
     dsm_params p;
     dsm_params_default(&p);
-    std::string prefixes = "", outprefix = "", devlist = "";
+    std::string prefixes = "", outprefix = "", devlist = "", exchange = "allgather";
     int device = 0;
     static option long_options[] = {{"pmin", required_argument, 0, 'P'},     {"pmax", required_argument, 0, 258},
                                     {"mindepth", required_argument, 0, 'm'}, {"emin", required_argument, 0, 'e'},
                                     {"emax", required_argument, 0, 'E'},     {"fmin", required_argument, 0, 'f'},
                                     {"maxdepth", required_argument, 0, 'M'}, {"prefix", required_argument, 0, 'p'},
                                     {"device", required_argument, 0, 257},   {"out-prefix", required_argument, 0, 259},
-                                    {"devices", required_argument, 0, 260},  {0, 0, 0, 0}};
+                                    {"devices", required_argument, 0, 260},  {"exchange", required_argument, 0, 261},
+                                    {0, 0, 0, 0}};
     int c, oi = 0;
     while ((c = getopt_long(argc, argv, "P:m:e:E:f:M:p:", long_options, &oi)) != -1) {
         switch (c) {
@@ -220,6 +363,7 @@ int main(int argc, char** argv) {
             case 257: device = atoi(optarg); break;
             case 259: outprefix = optarg; break;
             case 260: devlist = optarg; break;
+            case 261: exchange = optarg; break;
             default: std::cerr << USAGE << std::endl; return 1;
         }
     }
@@ -238,7 +382,8 @@ int main(int argc, char** argv) {
         std::string one;
         while (std::getline(ss, one, ',')) devs.push_back(atoi(one.c_str()));
         std::vector<std::string> files(argv + optind, argv + argc);
-        if (devs.empty()) { std::cerr << USAGE << std::endl; return 1; }
+        if (devs.empty() || (exchange != "allgather" && exchange != "owner")) { std::cerr << USAGE << std::endl; return 1; }
+        if (exchange == "owner") return run_devices_owner(devs, p, pre, files, outprefix);
         return run_devices(devs, p, pre, files, outprefix);
     }
     std::vector<dsm_index*> idx;

@@ -52,6 +52,13 @@ def test_dsm_node_device_list_runs_the_exchange_on_rccl(golden, tmp_path):
     assert r.returncode == 0, r.stderr
     for p in ("A", "GT"):
         assert open(tmp_path / ("o." + p + ".txt"), "rb").read() == golden.server_out("toy3", "default", p)
+    # owner mode (--exchange owner: prefix k merged by device k mod G alone; lanes, gate, ncclSend/Recv + ncclBroadcast callbacks),
+    # with the world of one rank a test box allows: plain, and with every level forced through the gather / broadcast
+    for env in (dict(os.environ, DSM_FORCE_EXCHANGE="1"), dict(os.environ)):
+        r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0", "--exchange", "owner", "-E", "2.0", "-f", "2", "-p", ",".join(ps)] + fmis,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want and b"owner mode" in r.stderr
     # samples must divide evenly among the devices
     r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0,0", "-E", "2.0", "-p", "A"] + fmis, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 1 and b"multiple of the number of devices" in r.stderr
