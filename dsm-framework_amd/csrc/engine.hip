@@ -217,6 +217,8 @@ struct ExpandArgs {
                       // bit 2 (one sample): the level's nodes are tested for output here -- everything in metaserver.cpp:406-419 that does
                       // not depend on the node (depth, pmin, the entropy thresholds against the 0 a single frequency gives) holds;
                       // bit 3 (one sample): a tile's planes form a 64-byte line {plane[4], candidate bits, candidates | pairs << 32, -, -}
+    u32 cstride;      // packed column: distance, in words, between the entries of consecutive nodes (1, or the number of local samples
+                      // when the level is node-major, see Xchg::nm)
     u32 w16;          // this level's column: 0 = frequencies as P plus a flag byte; 1 = 16-bit frequencies plus a flag byte (every
                       // frequency of the level is below 65535); 2 = ONE 16-bit word per node, frequency in bits 0-8 and the flags
                       // in bits 9-15 (every frequency below 512: all but the top levels of a prefix)
@@ -585,7 +587,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     if (i < a.F) {
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16 == 2) {
-            reinterpret_cast<u16*>(valf)[i] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
+            reinterpret_cast<u16*>(valf)[(size_t)i * a.cstride] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
         } else {
             if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
             else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
@@ -731,7 +733,12 @@ struct Xchg {
     u64 F;        // nodes of the level
     u32 fb;       // bytes per frequency entry: 2 when every frequency of the level is below 65535, else sizeof(P); 1 = packed: one
                   // 16-bit word per node and nothing else (frequency below 512 in bits 0-8, the flag byte in bits 9-15)
+    u32 nm;       // packed levels of several local samples: node-major inside a rank -- the words of node v in the rank's samples are
+                  // adjacent ([F][nlocal] instead of [nlocal][F]): whoever looks at a node across the samples (reduce, predicates,
+                  // reader-set orders, candidate store) reads one 2 * nlocal-byte piece instead of nlocal strided 2-byte entries
 };
+// place of the packed word of node v in local sample l of a rank
+__device__ __forceinline__ u64 x_word_index(const Xchg& x, u32 l, u64 v) { return x.nm ? v * x.nlocal + l : (u64)l * x.F + v; }
 __device__ __forceinline__ void x_split(const Xchg& x, u32 g, u32& r, u32& l) {
     if (x.nlocal == 1) { r = g; l = 0; }          // one sample per rank (multi-GPU runs)
     else if (x.d == x.nlocal) { r = 0; l = g; }   // single process
@@ -742,7 +749,7 @@ __device__ __forceinline__ P x_freq(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
     const u8* rb = x.base + (u64)r * x.bpr + XHDR;
-    if (x.fb == 1) return (P)(reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v] & (PACK_FMAX - 1));
+    if (x.fb == 1) return (P)(reinterpret_cast<const u16*>(rb)[x_word_index(x, l, v)] & (PACK_FMAX - 1));
     if (x.fb == 2) return (P)reinterpret_cast<const u16*>(rb)[(u64)l * x.F + v];
     return reinterpret_cast<const P*>(rb)[(u64)l * x.F + v];
 }
@@ -750,9 +757,17 @@ template <typename P>
 __device__ __forceinline__ u32 x_pl(const Xchg& x, u32 g, u64 v) {
     u32 r, l;
     x_split(x, g, r, l);
-    if (x.fb == 1) return (u32)reinterpret_cast<const u16*>(x.base + (u64)r * x.bpr + XHDR)[(u64)l * x.F + v] >> 9;
+    if (x.fb == 1) return (u32)reinterpret_cast<const u16*>(x.base + (u64)r * x.bpr + XHDR)[x_word_index(x, l, v)] >> 9;
     const u8* rb = x.base + (u64)r * x.bpr + XHDR + (u64)x.nlocal * x.F * x.fb;
     return rb[(u64)l * x.F + v];
+}
+
+// eight local samples of a single process on a packed node-major level: the node's eight words as one 16-byte piece
+__device__ __forceinline__ bool x_is_nm8(const Xchg& x) { return x.nm && x.fb == 1 && x.nlocal == 8 && x.d == 8; }
+__device__ __forceinline__ void x_words8(const Xchg& x, u64 v, u32 w[8]) {
+    const uint4 q = reinterpret_cast<const uint4*>(x.base + XHDR)[v];
+    w[0] = q.x & 0xFFFFu; w[1] = q.x >> 16; w[2] = q.y & 0xFFFFu; w[3] = q.y >> 16;
+    w[4] = q.z & 0xFFFFu; w[5] = q.z >> 16; w[6] = q.w & 0xFFFFu; w[7] = q.w >> 16;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -772,8 +787,19 @@ __device__ __forceinline__ void parent_eval(const Xchg& x, u32 u, u32 nT4[4]) {
     for (u32 r = 0; r < world; ++r) {
         if (x.fb == 1) {  // packed columns: the children nibble sits in bits 9-12 of the node's word
             const u16* pw = reinterpret_cast<const u16*>(x.base + (u64)r * x.bpr + XHDR);
+            if (x.nm && x.nlocal == 8) {  // eight samples per rank: the node's words are one 16-byte piece
+                const uint4 q = reinterpret_cast<const uint4*>(pw)[u];
+                const u32 w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 m0 = (w4[k] >> 9) & 15u, m1 = w4[k] >> 25;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) nT4[c] += ((m0 >> c) & 1u) + ((m1 >> c) & 1u);
+                }
+                continue;
+            }
             for (u32 l = 0; l < x.nlocal; ++l) {
-                const u32 m = (u32)pw[(u64)l * x.F + u] >> 9;
+                const u32 m = (u32)pw[x_word_index(x, l, u)] >> 9;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) nT4[c] += (m >> c) & 1u;
             }
@@ -840,13 +866,28 @@ __device__ __forceinline__ bool filter_node(const FilterArgs& a, const Xchg& x, 
     u64 sumN = a.d;
     double s = 0;
     u32 l = 0xFF;
-    for (u32 g = 0; g < a.d; ++g) {
-        u64 f = (u64)x_freq<P>(x, g, v);
-        if (f) {
-            u32 lg = x_pl<P>(x, g, v) >> 4;
-            l = l == 0xFF ? lg : (l == lg ? l : 5u);
-            sumN += f;
-            if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+    if (x_is_nm8(x)) {
+        u32 w[8];
+        x_words8(x, v, w);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const u64 f = w[g] & (PACK_FMAX - 1);
+            if (f) {
+                const u32 lg = w[g] >> 13;
+                l = l == 0xFF ? lg : (l == lg ? l : 5u);
+                sumN += f;
+                if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+            }
+        }
+    } else {
+        for (u32 g = 0; g < a.d; ++g) {
+            u64 f = (u64)x_freq<P>(x, g, v);
+            if (f) {
+                u32 lg = x_pl<P>(x, g, v) >> 4;
+                l = l == 0xFF ? lg : (l == lg ? l : 5u);
+                sumN += f;
+                if (a.emax > 0) s += (double)(f + 1) * (double)__log2f((float)(f + 1));
+            }
         }
     }
     if (l >= 1 && l <= 4) return false;
@@ -1255,11 +1296,18 @@ __global__ __launch_bounds__(256) void order_kernel(u32 F, Xchg x, const u16* __
         const u64 ord = order[u];
         u64 mbyid = 0;  // 4 presence bits per reader id (ids < 16)
         u32 um = 0;     // children of the node in the union
-        for (u32 k = 0; k < cnt; ++k) {
-            const u32 r = (u32)((ord >> (4 * k)) & 15);
-            const u32 m = x_pl<P>(x, r, u) & 15u;  // which children this reader continues into
-            mbyid |= (u64)m << (4 * r);
-            um |= m;
+        if (x_is_nm8(x)) {  // (a sample that does not hold the node has an empty word: no children)
+            u32 w[8];
+            x_words8(x, u, w);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { const u32 m = (w[g] >> 9) & 15u; mbyid |= (u64)m << (4 * g); um |= m; }
+        } else {
+            for (u32 k = 0; k < cnt; ++k) {
+                const u32 r = (u32)((ord >> (4 * k)) & 15);
+                const u32 m = x_pl<P>(x, r, u) & 15u;  // which children this reader continues into
+                mbyid |= (u64)m << (4 * r);
+                um |= m;
+            }
         }
         if (um && !(um & (um - 1))) {  // one child: the readers that enter it, last one first
             u64 rev = 0;
@@ -2722,6 +2770,8 @@ class Engine {
         x.nlocal = (u32)nlocal;
         x.d = d;
         x.F = F_;
+        x.fb = 0;
+        x.nm = 0;
         return x;
     }
 
@@ -2860,6 +2910,8 @@ class Engine {
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
             ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w9 ? 2u : (w16 ? 1u : 0u);
+            const bool nm = w9 && nlocal > 1 && !trie_mode;  // node-major packed columns (Xchg::nm)
+            ea.cstride = nm ? (u32)nlocal : 1u;
             if (dynamic) {
                 ea.dyn = d_dyn;
                 ea.dyn_mask = pack_columns ? 3u : 1u;
@@ -2917,7 +2969,7 @@ class Engine {
                     es.splane = (depth & 1) ? splane2[s] : splane[s];
                     es.pplane = (depth & 1) ? splane[s] : splane2[s];
                 }
-                es.valf = send + XHDR + (size_t)s * F * (w9 ? 2u : fb);         // this sample's frequency column (packed: its words)
+                es.valf = send + XHDR + (nm ? (size_t)s * 2 : (size_t)s * F * (w9 ? 2u : fb));  // this sample's frequency column (packed: its words)
                 es.pl = send + XHDR + (size_t)nlocal * F * fb + (size_t)s * F;   // children nibble | left char << 4 (not used when packed)
                 for (int c = 0; c < 4; ++c) es.cost[c] = m.lfcost[c];
                 for (int c = 0; c < 4; ++c) es.sb.sb0[c] = m.C[(int)(unsigned char)bases[c]];  // superblock 0: nothing before it
@@ -3057,6 +3109,7 @@ class Engine {
             }
             Xchg x = xview(xcur, F, bpr);
             x.fb = fb;
+            x.nm = (w9 && nlocal > 1 && !trie_mode) ? 1u : 0u;
             // ---- union frontier of the next level -------------------------------------------------
             LevelHost& me = L[depth];
             LevelHost child;
