@@ -2503,14 +2503,6 @@ class Engine {
     u64* order[2] = {nullptr, nullptr};
     u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_wsum = nullptr, *cand_wscan = nullptr, *scan_tmp64 = nullptr;  // per wave of 64 nodes: candidates | pairs << 32, and their scan
-    // The candidate store of a level is off the critical path (nothing of the following levels reads it): it runs on a side stream
-    // next to the following level's LF-step launch, from its own copy of the scan (two buffers, by level parity), and the launch two
-    // levels on -- the one that overwrites the level's columns -- waits for it.
-    u64* cand_wscan2[2] = {nullptr, nullptr};
-    hipStream_t aux = nullptr;
-    hipEvent_t aux_go = nullptr, aux_done[2] = {nullptr, nullptr};
-    bool aux_pending[2] = {false, false};
-    bool side_store = false;
     u64* d_counters = nullptr;
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
@@ -2539,9 +2531,6 @@ class Engine {
         }
         for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
-        if (aux_go) (void)hipEventDestroy(aux_go);
-        for (auto e : aux_done) if (e) (void)hipEventDestroy(e);
         if (fill_done) (void)hipEventDestroy(fill_done);
         for (auto e : chunk_filled) if (e) (void)hipEventDestroy(e);
     }
@@ -2722,15 +2711,6 @@ class Engine {
         if (int rc = dalloc(samechild, Fcap)) return rc;
         if (int rc = dalloc(cand_wsum, nwave + 8)) return rc;
         if (int rc = dalloc(cand_wscan, nwave + 8)) return rc;
-        // (one sample only: with several, the store also reads the level's reader counts and orders, which the next level's sweep reuses)
-        side_store = d == 1 && !multi && !stream_mode && !trie_mode && !getenv("DSM_NO_SIDE_STORE");
-        if (side_store) {
-            cand_wscan2[0] = cand_wscan;
-            if (int rc = dalloc(cand_wscan2[1], nwave + 8)) return rc;
-            DSM_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-            DSM_HIP(hipEventCreateWithFlags(&aux_go, hipEventDisableTiming));
-            for (int k = 0; k < 2; ++k) DSM_HIP(hipEventCreateWithFlags(&aux_done[k], hipEventDisableTiming));
-        }
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(nwave) + 8)) return rc;
         if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
         if (int rc = dalloc(d_totals, 8)) return rc;
@@ -2831,7 +2811,6 @@ class Engine {
         DSM_HIP(hipSetDevice(device));
         for (int s_ = 0; s_ < nlocal && !trie_mode; ++s_)
             if (!idx[s_]->dev.blk) return fail(DSM_E_INVAL, "an index of this miner is offloaded: dsm_index_reload first");
-        if (aux) { DSM_HIP(hipStreamSynchronize(aux)); aux_pending[0] = aux_pending[1] = false; }  // (a run that failed may have left work there)
         arena.off = 0;
         earena.off = 0;
         bool emitting = emit;       // cleared when this rank's emission side runs out of memory in a multi-rank run
@@ -2958,10 +2937,6 @@ class Engine {
             }
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
-            if (side_store && aux_pending[depth & 1]) {  // the candidate store of the level two above reads the columns this launch overwrites
-                DSM_HIP(hipStreamWaitEvent(st, aux_done[depth & 1], 0));
-                aux_pending[depth & 1] = false;
-            }
             std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
             ExpandChain::Link& link = g_expand_chain.dev[device];
             if (link.last && link.owner != this) DSM_HIP(hipStreamWaitEvent(st, link.last, 0));
@@ -3416,7 +3391,7 @@ class Engine {
         const FilterArgs fa = filter_args(F, depth, order_mode);
         if (run_kernel)  // (single-tile levels; larger ones evaluate the predicates inside the advance sweep)
             hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild, me.cand_bits, cand_wsum);
-        exclusive_scan<u64, u64>(cand_wsum, side_store ? cand_wscan2[depth & 1] : cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
+        exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
         return 0;
     }
     int emit_store(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {  // after the level's synchronisation
@@ -3433,17 +3408,10 @@ class Engine {
             EARENA_GET(me.ids, u32, me.npairs);
             EARENA_GET(me.freqs, u64, me.npairs);
             me.ncand = nc;
-            if (side_store) {  // (everything the store reads was written before the level's publish kernel, which the host has seen)
-                DSM_HIP(hipEventRecord(aux_go, st));
-                DSM_HIP(hipStreamWaitEvent(aux, aux_go, 0));
-                hipLaunchKernelGGL((cand_store_kernel<P>), grid_npt(F), dim3(256), 0, aux, fa, xp, nT[cur], order[cur], order16[cur], me.cand_bits,
-                                   cand_wscan2[depth & 1], me.cand_node, me.cand_poff, me.ids, me.freqs);
-                DSM_HIP(hipEventRecord(aux_done[depth & 1], aux));
-                aux_pending[depth & 1] = true;
-            } else {
-                hipLaunchKernelGGL((cand_store_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_bits, cand_wscan,
-                                   me.cand_node, me.cand_poff, me.ids, me.freqs);
-            }
+            // (tried on a side stream next to the following level's LF-step launch -- nothing after it reads the store: the event
+            // waits between the streams cost more than the overlap returned, device time +7 ms per pass)
+            hipLaunchKernelGGL((cand_store_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], order[cur], order16[cur], me.cand_bits, cand_wscan,
+                               me.cand_node, me.cand_poff, me.ids, me.freqs);
         }
         stats.candidates += me.ncand;
         return 0;
@@ -3457,8 +3425,6 @@ class Engine {
         if (ncand_total == 0) return 0;
         if (ncand_total > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "more than 2^32 candidate tuples in one prefix: use a longer prefix");
         const u32 nt = (u32)ncand_total;
-        for (int k = 0; k < 2 && side_store; ++k)
-            if (aux_pending[k]) { DSM_HIP(hipStreamWaitEvent(st, aux_done[k], 0)); aux_pending[k] = false; }
         // bottom-up: candidates in subtree
         for (u32 l = nlev; l-- > 1;) {
             EARENA_GET(L[l].sub, u32, L[l].n);
