@@ -2998,7 +2998,10 @@ class Engine {
     } while (0)
                 if (self_mode) {  // several samples: one launch for up to BATCH_MAX of this process's
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;
-                    u32 gx = 2 * expand_blocks / (u32)nb;
+                    // (measured with eight samples: 2 x resident -> 1255, 4 x -> 1219, 8 x -> 1189, 16 x -> 1184, 32 x -> 1198 ms per pass: the samples'
+                    // sweeps finish unevenly, shorter wave strides even them out)
+                    static const u32 grid_factor = getenv("DSM_BATCH_GRID_FACTOR") ? (u32)atoi(getenv("DSM_BATCH_GRID_FACTOR")) : 8u;
+                    u32 gx = (grid_factor ? grid_factor : 8u) * expand_blocks / (u32)nb;
                     if (gx < 1) gx = 1;
                     const dim3 bg(need < gx ? need : gx, (u32)nb);
 #define DSM_LAUNCH_BATCH(SB, IC, OC) hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), bg, dim3(256), 0, st, eb, ea, d_counters, d_childmax)
