@@ -617,6 +617,9 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const u32 ntile = (a.F + 63) >> 6;
     ExpandAcc acc;
+#ifdef DSM_CLOCK_PROBE
+    const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
+#endif
     // prologue of the pipeline: heads of the wave's first tile, handles of its second
     u32 rn = DEAD;
     {
@@ -642,6 +645,12 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
                 expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss);
         }
     }
+#ifdef DSM_CLOCK_PROBE
+    if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
+        atomicAdd((unsigned long long*)&counters[6], (unsigned long long)(__builtin_readcyclecounter() - probe_c0));
+        atomicAdd((unsigned long long*)&counters[7], (unsigned long long)(wall_clock64() - probe_r0));
+    }
+#endif
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
     if (__any(acc.wide != 0) && lane == 0) atomicMax(childmax, __any((acc.wide & 2u) != 0) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
     {
@@ -3367,6 +3376,9 @@ class Engine {
             DSM_HIP(hipMemcpy(sh.data(), d_counters, sh.size() * sizeof(u64), hipMemcpyDeviceToHost));
             for (int k = 0; k < COUNTER_SHARDS; ++k)
                 for (int c = 0; c < NCOUNTERS; ++c) hc[c] += sh[(size_t)k * 8 + c];
+#ifdef DSM_CLOCK_PROBE
+            if (sh[7]) fprintf(stderr, "clock probe: %.1f MHz over %.2f ms of LF-step sweeps\n", (double)sh[6] / (double)sh[7] * 100.0, (double)sh[7] * 1e-5);
+#endif
         }
         stats.reported += hc[0];
         stats.lf_steps += hc[1];
@@ -4064,6 +4076,465 @@ int dsm_merge(dsm_trie* const* tries, int n, const dsm_params* p, dsm_tuple_sink
     if (wide) return merge_impl<u64>(tries, n, &q, sink, ctx, stats);
     return merge_impl<u32>(tries, n, &q, sink, ctx, stats);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dsm_server: one metaserver -- d connections whose streams are merged WHILE they arrive (metaserver.cpp:682-739 reads its
+// sockets token by token inside traverse(), so it holds no stream and prints a node as soon as every client has closed it).
+// A level-synchronous merge needs whole subtrees, so the unit here is the subtree of a node of depth prefix_len + 1: every client
+// of one server enforces the same prefix (metaenumerate.cpp:268-309, EnumerateQuery.cpp:240-290), above that depth a stream is a
+// single path, and a unit is final in a stream once the stream has closed it, gone past it, or ended.  As soon as that holds for
+// every connection the unit's entries -- a range of every deeper level, the levels being in path order -- leave the streams'
+// device windows as compact tries and are merged and printed (run_auto with the enforced path down to the unit and, as the
+// reader-set order of its root, the one a shallow pass over the nodes above gives: it depends on earlier siblings only,
+// metaserver.cpp:322-339) while the later units are still being received; the nodes of the enforced path, which close last, follow
+// at the end.  The card holds the units in flight, not d complete tries.  prefix_len < 0: the classic way (merge after the last
+// stream has ended; also what a stream that is not a single path above the unit depth would need -- such a stream is refused).
+// ---------------------------------------------------------------------------------------------------------------------------
+}  // extern "C" (the helpers below are templates)
+namespace dsm {
+__global__ void fc_rebase_kernel(u32* fc, size_t n, u32 delta) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fc[i] -= delta;
+}
+struct ServerOrder {  // Engine<P>::NodeOrder without the position type
+    u32 depth = 0;
+    std::vector<u32> sym;
+    std::vector<std::vector<u16>> ord;
+};
+// one engine run over the given tries (sample id = position): capture (shallow pass, nothing emitted), a unit (run_auto: a unit that
+// does not fit the buffers splits like any prefix) or the closing pass over the depths lo..hi
+template <typename P>
+static int server_run_t(dsm_trie* const* tr, int n, const dsm_params& q, const std::string& prefix, dsm_tuple_sink sink, void* ctx, bool emit,
+                        u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out) {
+    std::unique_ptr<MinerT<P>> m(new MinerT<P>());
+    int rc = m->e.init_tries(tr, n, q);
+    if (rc) return rc;
+    typename Engine<P>::NodeOrder sd, cp;
+    if (seed) { sd.depth = seed->depth; sd.sym = seed->sym; sd.ord = seed->ord; }
+    if (capture) cp.depth = capture->depth;
+    if (capture || hi != ~0u) rc = m->e.run(prefix.c_str(), sink, nullptr, ctx, emit, lo, hi, expand_cap, seed ? &sd : nullptr, capture ? &cp : nullptr, capture == nullptr);
+    else rc = m->run_auto(prefix, sink, ctx, emit, lo, seed ? &sd : nullptr);
+    const int rc2 = m->e.finish_emits();
+    if (capture) { capture->sym = cp.sym; capture->ord = cp.ord; }
+    if (out) *out = m->e.stats;
+    return rc ? rc : rc2;
+}
+static int server_run(bool wide, dsm_trie* const* tr, int n, const dsm_params& q, const std::string& prefix, dsm_tuple_sink sink, void* ctx,
+                      bool emit, u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out) {
+    return wide ? server_run_t<u64>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out)
+                : server_run_t<u32>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out);
+}
+}  // namespace dsm
+
+extern "C" {
+struct dsm_server {
+    struct DevLevel {
+        dsm::u64* freq = nullptr;
+        dsm::u8* pl = nullptr;
+        dsm::u32* fc = nullptr;
+        size_t n = 0, cap = 0;
+        dsm::u64 abs0 = 0;  // index, inside its level of the stream, of the first entry held
+        void release() {
+            if (freq) (void)hipFree(freq);
+            if (pl) (void)hipFree(pl);
+            if (fc) (void)hipFree(fc);
+            freq = nullptr; pl = nullptr; fc = nullptr; n = cap = 0;
+        }
+    };
+    struct Stream {
+        dsm::StreamParser sp;
+        std::mutex mu;                 // the connection's reader thread (feed) against the merger (taking a unit out)
+        std::vector<DevLevel> dl;      // levels below the unit depth: what has been uploaded and not yet left with a unit
+        std::vector<dsm::u64> from;    // first entry, per level below the unit depth, of the next unit to leave
+        size_t taken = 0;              // units of this stream that have left
+        bool ended = false;
+        dsm_trie_stream* classic = nullptr;  // prefix_len < 0: the whole stream, merged at the end
+        dsm_trie* whole = nullptr;
+    };
+    int d = 0, device = 0;
+    int K = -1;          // length of the enforced prefix; units are the nodes of depth U = K + 1
+    dsm::u32 U = 0;
+    size_t WINDOW = 1u << 16;
+    dsm_params prm;
+    dsm_tuple_sink sink = nullptr;
+    void* ctx = nullptr;
+    std::vector<std::unique_ptr<Stream>> s;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread merger;
+    bool quit = false, done = false;
+    int rc = 0;
+    std::string err;
+    dsm_stats stats;
+    dsm::u64 units_merged = 0, peak_unit_nodes = 0;
+
+    ~dsm_server() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        if (merger.joinable()) merger.join();
+        (void)hipSetDevice(device);
+        for (auto& st : s) {
+            for (DevLevel& v : st->dl) v.release();
+            if (st->classic) dsm_trie_stream_abort(st->classic);
+            if (st->whole) dsm_trie_free(st->whole);
+        }
+    }
+    int grow(DevLevel& v, size_t need) {
+        using namespace dsm;
+        if (need <= v.cap) return 0;
+        size_t cap = v.cap ? v.cap * 2 : WINDOW;
+        if (cap < need) cap = need;
+        DevLevel w;
+        hipError_t e = hipMalloc((void**)&w.freq, cap * sizeof(u64));
+        if (e == hipSuccess) e = hipMalloc((void**)&w.pl, cap);
+        if (e == hipSuccess) e = hipMalloc((void**)&w.fc, cap * sizeof(u32));
+        if (e == hipSuccess && v.n) {
+            e = hipMemcpy(w.freq, v.freq, v.n * sizeof(u64), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(w.pl, v.pl, v.n, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(w.fc, v.fc, v.n * sizeof(u32), hipMemcpyDeviceToDevice);
+        }
+        if (e != hipSuccess) { w.release(); return fail(DSM_E_NOMEM, std::string("dsm_server: ") + hipGetErrorString(e)); }
+        w.n = v.n; w.cap = cap; w.abs0 = v.abs0;
+        v.release();
+        v = w;
+        return 0;
+    }
+    // final entries of the levels below the unit depth go to the card (whole windows, or everything); caller holds st.mu
+    int upload(Stream& st, bool all) {
+        using namespace dsm;
+        if (st.dl.size() < st.sp.L.size()) st.dl.resize(st.sp.L.size());
+        for (size_t l = (size_t)U + 1; l < st.sp.L.size(); ++l) {
+            const size_t k = (size_t)(st.sp.final_count(l) - st.sp.base[l]);
+            if (k == 0 || (!all && k < WINDOW)) continue;
+            DevLevel& v = st.dl[l];
+            if (int r = grow(v, v.n + k)) return r;
+            const HostTrieLevel& h = st.sp.L[l];
+            DSM_HIP(hipMemcpy(v.freq + v.n, h.freq.data(), k * sizeof(u64), hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.pl + v.n, h.pl.data(), k, hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.fc + v.n, h.fc.data(), k * sizeof(u32), hipMemcpyHostToDevice));
+            v.n += k;
+            st.sp.drop_front(l, k);
+        }
+        return 0;
+    }
+    // a trie of the nodes above the unit depth and, at the unit depth, the given roots: what a shallow pass needs.  `final`: the
+    // path nodes carry their own frequencies and left chars (they have closed), otherwise place holders (nothing prints them)
+    int hollow(Stream& st, int upto_sym, bool final, dsm_trie** out) {
+        using namespace dsm;
+        std::vector<u64> f; std::vector<u8> pl; std::vector<u32> fc;
+        std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
+        t->device = device;
+        const size_t clen = st.sp.chain_sym.size();  // nodes of depth 1 .. clen exist on the path (clen <= K)
+        std::vector<const UnitMark*> roots;
+        for (const UnitMark& um : st.sp.unit_closed) if ((int)um.sym <= upto_sym) roots.push_back(&um);
+        u32 rootmask = 0;
+        for (const UnitMark* um : roots) rootmask |= 1u << um->sym;
+        for (size_t l = 0; l <= clen; ++l) {  // level l: the path node of depth l (0 = the root)
+            t->level_off.push_back(f.size());
+            const bool end = l == (size_t)K;   // its children are the units
+            u32 kids = end ? rootmask : (l < clen ? 1u << st.sp.chain_sym[l] : 0u);
+            u64 fr = l ? 1 : 0;
+            u32 code = 0;
+            if (final && l >= 1 && l - 1 < st.sp.chain.size() && st.sp.chain[l - 1].closed) { fr = st.sp.chain[l - 1].freq; code = st.sp.chain[l - 1].pl >> 4; }
+            f.push_back(fr); pl.push_back((u8)(kids | (code << 4))); fc.push_back(0);
+        }
+        if (clen == (size_t)K && !roots.empty()) {
+            t->level_off.push_back(f.size());
+            for (const UnitMark* um : roots) { f.push_back(um->freq); pl.push_back(um->pl); fc.push_back(0); if (um->freq > t->maxfreq) t->maxfreq = um->freq; }
+        }
+        t->level_off.push_back(f.size());
+        t->nodes = f.size();
+        DSM_HIP(hipMalloc((void**)&t->d_freq, f.size() * sizeof(u64)));
+        DSM_HIP(hipMalloc((void**)&t->d_pl, f.size()));
+        DSM_HIP(hipMalloc((void**)&t->d_fc, f.size() * sizeof(u32)));
+        DSM_HIP(hipMemcpy(t->d_freq, f.data(), f.size() * sizeof(u64), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_pl, pl.data(), f.size(), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_fc, fc.data(), f.size() * sizeof(u32), hipMemcpyHostToDevice));
+        *out = t.release();
+        return 0;
+    }
+    // the next unit of the stream leaves its windows as a compact trie: path, root, and its range of every deeper level.  Caller holds st.mu
+    int take_unit(Stream& st, dsm_trie** out) {
+        using namespace dsm;
+        const UnitMark& um = st.sp.unit_closed[st.taken];
+        if (int r = upload(st, true)) return r;
+        std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
+        t->device = device;
+        const size_t nl = um.upto.size();  // levels below the unit depth that existed when the unit closed
+        if (st.from.size() < nl) st.from.resize(nl, 0);
+        u64 tot = (u64)U + 1;
+        for (size_t k = 0; k < nl; ++k) {
+            if (um.upto[k] < st.from[k]) return fail(DSM_E_HIP, "dsm_server: unit marks out of order");
+            tot += um.upto[k] - st.from[k];
+        }
+        DSM_HIP(hipMalloc((void**)&t->d_freq, tot * sizeof(u64)));
+        DSM_HIP(hipMalloc((void**)&t->d_pl, tot));
+        DSM_HIP(hipMalloc((void**)&t->d_fc, tot * sizeof(u32)));
+        std::vector<u64> f; std::vector<u8> pl; std::vector<u32> fc;
+        for (u32 l = 0; l <= U; ++l) {
+            t->level_off.push_back(l);
+            if (l == U) { f.push_back(um.freq); pl.push_back(um.pl); fc.push_back(0); }
+            else { f.push_back(l ? 1 : 0); pl.push_back((u8)(1u << (l + 1 == U ? um.sym : st.sp.chain_sym[l]))); fc.push_back(0); }
+        }
+        DSM_HIP(hipMemcpy(t->d_freq, f.data(), f.size() * sizeof(u64), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_pl, pl.data(), f.size(), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_fc, fc.data(), f.size() * sizeof(u32), hipMemcpyHostToDevice));
+        u64 o = (u64)U + 1;
+        for (size_t k = 0; k < nl; ++k) {
+            const size_t l = (size_t)U + 1 + k;
+            const u64 a = st.from[k], b = um.upto[k], cnt = b - a;
+            if (cnt == 0) break;  // (a level without entries of this unit: none deeper either)
+            t->level_off.push_back(o);
+            DevLevel& v = st.dl[l];
+            if (v.abs0 != a || v.abs0 + v.n < b) return fail(DSM_E_HIP, "dsm_server: a unit's entries are not in the device window");
+            DSM_HIP(hipMemcpy(t->d_freq + o, v.freq, cnt * sizeof(u64), hipMemcpyDeviceToDevice));
+            DSM_HIP(hipMemcpy(t->d_pl + o, v.pl, cnt, hipMemcpyDeviceToDevice));
+            DSM_HIP(hipMemcpy(t->d_fc + o, v.fc, cnt * sizeof(u32), hipMemcpyDeviceToDevice));
+            const u64 child_from = k + 1 < nl ? st.from[k + 1] : 0;  // entries of the next level count from the unit's first one
+            if (child_from) hipLaunchKernelGGL(fc_rebase_kernel, grid_for(cnt), dim3(256), 0, 0, t->d_fc + o, (size_t)cnt, (u32)child_from);
+            // what is left of the level (entries of later units) moves to a window of its own
+            const size_t rest = v.n - (size_t)cnt;
+            DevLevel w;
+            if (rest) {
+                if (int r = grow(w, rest)) return r;
+                DSM_HIP(hipMemcpy(w.freq, v.freq + cnt, rest * sizeof(u64), hipMemcpyDeviceToDevice));
+                DSM_HIP(hipMemcpy(w.pl, v.pl + cnt, rest, hipMemcpyDeviceToDevice));
+                DSM_HIP(hipMemcpy(w.fc, v.fc + cnt, rest * sizeof(u32), hipMemcpyDeviceToDevice));
+                w.n = rest;
+            }
+            w.abs0 = b;
+            DSM_HIP(hipDeviceSynchronize());
+            v.release();
+            v = w;
+            o += cnt;
+        }
+        DSM_HIP(hipDeviceSynchronize());
+        t->level_off.push_back(o);
+        t->nodes = o;
+        t->maxfreq = st.sp.mf;
+        for (size_t k = 0; k < nl; ++k) st.from[k] = um.upto[k];
+        ++st.taken;
+        *out = t.release();
+        return 0;
+    }
+    // is the unit with symbol c final in the stream?  (caller holds st.mu)
+    static bool past(const Stream& st, int c) {
+        if (st.ended) return true;
+        for (const dsm::UnitMark& um : st.sp.unit_closed) if ((int)um.sym >= c) return true;
+        return !st.sp.unit_opened.empty() && (int)st.sp.unit_opened.back() > c;
+    }
+    void add_stats(const dsm_stats& a, dsm::u64 path_nodes) {
+        stats.tuples += a.tuples; stats.pairs += a.pairs; stats.candidates += a.candidates;
+        stats.union_nodes += a.union_nodes >= path_nodes ? a.union_nodes - path_nodes : 0;
+        stats.levels += a.levels; stats.device_ms += a.device_ms; stats.host_ms += a.host_ms; stats.splits += a.splits;
+        if (a.max_frontier > stats.max_frontier) stats.max_frontier = a.max_frontier;
+        stats.pair_order_exact = a.pair_order_exact;
+    }
+    std::string path_text(const Stream& st) const {
+        std::string p;
+        for (dsm::u8 c : st.sp.chain_sym) p += "ACGT"[c];
+        return p;
+    }
+    // one unit, every stream past it: out of the windows, the order of its root from a shallow pass, merge, print
+    int merge_unit(int c) {
+        using namespace dsm;
+        DSM_HIP(hipSetDevice(device));
+        std::vector<dsm_trie*> unit(d, nullptr), hol(d, nullptr);
+        auto cleanup = [&] { for (auto* t : unit) if (t) dsm_trie_free(t); for (auto* t : hol) if (t) dsm_trie_free(t); };
+        std::string path;
+        bool wide = prm.wide != 0;
+        u64 nodes = 0;
+        int r = 0;
+        for (int k = 0; k < d && !r; ++k) {
+            Stream& st = *s[k];
+            std::lock_guard<std::mutex> lk(st.mu);
+            if (st.sp.chain_sym.size() == (size_t)K) {
+                const std::string mine = path_text(st);
+                if (path.empty()) path = mine;
+                else if (path != mine) r = fail(DSM_E_FORMAT, "dsm_server: the connections enforce different prefixes (" + path + " / " + mine + ")");
+            }
+            if (r) break;
+            if (st.sp.mf >= 0xFFFFFFF0ull) wide = true;
+            const bool has = st.taken < st.sp.unit_closed.size() && (int)st.sp.unit_closed[st.taken].sym == c;
+            r = hollow(st, c, false, &hol[k]);
+            if (!r) r = has ? take_unit(st, &unit[k]) : hollow(st, c - 1, false, &unit[k]);  // (a sample without the unit: its path, no root)
+            if (!r) nodes += unit[k]->nodes;
+        }
+        if (r) { cleanup(); return r; }
+        ServerOrder cap, seed;
+        cap.depth = U;
+        r = server_run(wide, hol.data(), d, prm, path, sink, ctx, false, 1, ~0u, U, nullptr, &cap, nullptr);
+        if (!r) {
+            size_t q = 0;
+            while (q < cap.sym.size() && (int)cap.sym[q] != c) ++q;
+            if (q == cap.sym.size()) r = fail(DSM_E_HIP, "dsm_server: the shallow pass did not find the unit");
+            else { seed.depth = U; seed.ord.push_back(cap.ord[q]); }
+        }
+        dsm_stats a;
+        memset(&a, 0, sizeof a);
+        if (!r) r = server_run(wide, unit.data(), d, prm, path + "ACGT"[c], sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);
+        if (!r) { add_stats(a, (u64)K); ++units_merged; if (nodes > peak_unit_nodes) peak_unit_nodes = nodes; }
+        cleanup();
+        return r;
+    }
+    // the nodes of the enforced path, after every unit and every stream's end
+    int merge_path() {
+        using namespace dsm;
+        if (K < 1) return 0;
+        DSM_HIP(hipSetDevice(device));
+        std::vector<dsm_trie*> hol(d, nullptr);
+        std::string path;
+        bool wide = prm.wide != 0;
+        int r = 0;
+        u64 roots = 0;
+        for (int k = 0; k < d && !r; ++k) {
+            Stream& st = *s[k];
+            std::lock_guard<std::mutex> lk(st.mu);
+            if (st.sp.chain_sym.size() == (size_t)K && path.empty()) path = path_text(st);
+            if (st.sp.mf >= 0xFFFFFFF0ull) wide = true;
+            r = hollow(st, 3, true, &hol[k]);
+        }
+        for (int k = 0; k < d; ++k) roots += s[k]->sp.unit_closed.size() ? 1 : 0;
+        dsm_stats a;
+        memset(&a, 0, sizeof a);
+        if (!r && !path.empty()) {
+            r = server_run(wide, hol.data(), d, prm, path, sink, ctx, true, 1, (u32)K, U, nullptr, nullptr, &a);
+            if (!r) {  // (the pass walked the path and the unit roots: the roots were counted with their units)
+                const u64 below = a.union_nodes >= (u64)K ? a.union_nodes - (u64)K : 0;
+                add_stats(a, below);
+            }
+        }
+        for (auto* t : hol) if (t) dsm_trie_free(t);
+        return r;
+    }
+    void merger_main() {
+        int next = 0;  // units with a smaller symbol have been merged
+        for (;;) {
+            int c = -1;
+            bool all_ended = true;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (quit || rc) return;
+                    // the smallest symbol, not merged yet, that some stream has opened as a unit -- ready when every stream is past it
+                    c = -1;
+                    all_ended = true;
+                    bool ready = true;
+                    for (int k = 0; k < d; ++k) {
+                        Stream& st = *s[k];
+                        std::lock_guard<std::mutex> sl(st.mu);
+                        all_ended = all_ended && st.ended;
+                        for (dsm::u8 o : st.sp.unit_opened) if ((int)o >= next && (c < 0 || (int)o < c)) c = (int)o;
+                    }
+                    if (c >= 0) {
+                        for (int k = 0; k < d && ready; ++k) {
+                            std::lock_guard<std::mutex> sl(s[k]->mu);
+                            ready = past(*s[k], c);
+                        }
+                        if (ready) break;
+                    } else if (all_ended) {
+                        break;
+                    }
+                    cv.wait(lk);
+                }
+            }
+            int r;
+            if (c >= 0) { r = merge_unit(c); next = c + 1; }
+            else r = merge_path();
+            std::lock_guard<std::mutex> lk(mu);
+            if (r) { rc = r; err = dsm_last_error(); cv.notify_all(); return; }
+            if (c < 0) { done = true; cv.notify_all(); return; }
+        }
+    }
+};
+
+int dsm_server_create(int nsamples, int device, int prefix_len, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_server** out) {
+    if (!out || !p || nsamples <= 0 || !sink) return fail(DSM_E_INVAL, "dsm_server_create: bad arguments");
+    *out = nullptr;
+    if (nsamples > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
+    if (prefix_len > 32) return fail(DSM_E_INVAL, "dsm_server_create: prefix_len > 32");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSM_E_NODEV, "dsm_server_create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_server_create: bad device ordinal");
+    std::unique_ptr<dsm_server> sv(new dsm_server());
+    sv->d = nsamples; sv->device = device; sv->K = prefix_len; sv->U = prefix_len >= 0 ? (u32)prefix_len + 1 : 0;
+    sv->prm = *p;
+    sv->prm.world_size = 1; sv->prm.rank = 0; sv->prm.fmin = 0; sv->prm.maxdepth = ~0u; sv->prm.prefix = "";  // as dsm_merge
+    sv->sink = sink; sv->ctx = ctx;
+    memset(&sv->stats, 0, sizeof sv->stats);
+    if (const char* e = getenv("DSM_TRIE_WINDOW")) { const long w = atol(e); if (w > 0) sv->WINDOW = (size_t)w; }
+    for (int k = 0; k < nsamples; ++k) {
+        sv->s.emplace_back(new dsm_server::Stream());
+        if (prefix_len >= 0) sv->s.back()->sp.unit_depth = sv->U;
+        else if (int rc = dsm_trie_stream_begin(device, &sv->s.back()->classic)) return rc;
+    }
+    if (prefix_len >= 0) { dsm_server* raw = sv.get(); sv->merger = std::thread([raw] { raw->merger_main(); }); }
+    *out = sv.release();
+    return DSM_OK;
+}
+int dsm_server_feed(dsm_server* sv, int sample, const uint8_t* bytes, size_t n) {
+    if (!sv || sample < 0 || sample >= sv->d || (!bytes && n)) return fail(DSM_E_INVAL, "dsm_server_feed: bad arguments");
+    dsm_server::Stream& st = *sv->s[sample];
+    if (st.classic) return dsm_trie_stream_feed(st.classic, bytes, n);
+    {
+        std::lock_guard<std::mutex> lk(sv->mu);
+        if (sv->rc) return fail(sv->rc, sv->err);
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        if (st.ended) return fail(DSM_E_INVAL, "dsm_server_feed: the connection has ended");
+        rc = st.sp.feed(bytes, n, false);
+        if (!rc) { DSM_HIP(hipSetDevice(sv->device)); rc = sv->upload(st, false); }
+    }
+    { std::lock_guard<std::mutex> lk(sv->mu); }  // (the merger is either before its look at the streams or already waiting)
+    sv->cv.notify_all();
+    return rc;
+}
+int dsm_server_end(dsm_server* sv, int sample) {
+    if (!sv || sample < 0 || sample >= sv->d) return fail(DSM_E_INVAL, "dsm_server_end: bad arguments");
+    dsm_server::Stream& st = *sv->s[sample];
+    if (st.classic) {
+        dsm_trie_stream* ts = st.classic;
+        st.classic = nullptr;
+        const int rc = dsm_trie_stream_end(ts, &st.whole);
+        if (!rc) st.ended = true;
+        return rc;
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        if (st.ended) return DSM_OK;
+        rc = st.sp.feed(nullptr, 0, true);
+        if (!rc) st.ended = true;
+    }
+    { std::lock_guard<std::mutex> lk(sv->mu); }
+    sv->cv.notify_all();
+    return rc;
+}
+int dsm_server_finish(dsm_server* sv, dsm_stats* stats) {
+    if (!sv) return fail(DSM_E_INVAL, "dsm_server_finish: null server");
+    for (auto& st : sv->s)
+        if (!st->ended) return fail(DSM_E_INVAL, "dsm_server_finish: a connection has not ended");
+    if (sv->K < 0) {
+        std::vector<dsm_trie*> tr;
+        for (auto& st : sv->s) tr.push_back(st->whole);
+        const int rc = dsm_merge(tr.data(), sv->d, &sv->prm, sv->sink, sv->ctx, &sv->stats);
+        if (stats) *stats = sv->stats;
+        return rc;
+    }
+    std::unique_lock<std::mutex> lk(sv->mu);
+    sv->cv.wait(lk, [&] { return sv->done || sv->rc; });
+    if (sv->rc) return fail(sv->rc, sv->err);
+    if (stats) *stats = sv->stats;
+    return DSM_OK;
+}
+uint64_t dsm_server_units(const dsm_server* sv, uint64_t* peak_unit_nodes) {
+    if (!sv) return 0;
+    if (peak_unit_nodes) *peak_unit_nodes = sv->peak_unit_nodes;
+    return sv->units_merged;
+}
+void dsm_server_destroy(dsm_server* sv) { delete sv; }
 
 int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // metaserver.cpp:472-484
     if (!b || !text || !len) return fail(DSM_E_INVAL, "dsm_format_batch: null argument");

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const InT* __
 }
 
 // out[i] = offsets[block] + exclusive prefix inside the tile.  in/out may alias.
-template <bool VEC, typename InT, typename OutT>
+// RAW: `offsets` holds the tiles' SUMS (what scan_reduce_kernel left), not their scan: a block adds up the sums of the tiles before
+// it by itself -- at most SCAN_TILE of them, a few KB that sit in L2 -- which saves the single-block launch that would scan them.
+template <bool VEC, typename InT, typename OutT, bool RAW = false>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const InT* in, OutT* out, size_t n, const OutT* __restrict__ offsets,
                                                                 OutT* __restrict__ total) {
     size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
@@ -83,9 +85,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const InT* in, 
     OutT s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
+    OutT off = 0;
+    if (RAW) {
+        OutT part = 0;
+        for (unsigned q = threadIdx.x; q < blockIdx.x; q += SCAN_THREADS) part += offsets[q];
+        OutT before;
+        block_exclusive_scan<OutT>(part, &before);
+        off = before;
+    } else if (offsets) {
+        off = offsets[blockIdx.x];
+    }
     OutT tot;
     OutT ex = block_exclusive_scan<OutT>(s, &tot);
-    OutT off = offsets ? offsets[blockIdx.x] : (OutT)0;
     ex += off;
     if (VEC && base + SCAN_ITEMS <= n) {
         ScanGroup<OutT> g;
@@ -128,6 +139,11 @@ inline void exclusive_scan(const InT* in, OutT* out, size_t n, OutT* tmp, OutT* 
     }
     if (vec) hipLaunchKernelGGL((scan_reduce_kernel<true, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
     else hipLaunchKernelGGL((scan_reduce_kernel<false, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, n, tmp);
+    if (nb <= (size_t)SCAN_TILE) {  // two launches: every block of the down-sweep adds up the sums before it (see RAW)
+        if (vec) hipLaunchKernelGGL((scan_down_kernel<true, InT, OutT, true>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, d_total);
+        else hipLaunchKernelGGL((scan_down_kernel<false, InT, OutT, true>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, d_total);
+        return;
+    }
     exclusive_scan<OutT, OutT>(tmp, tmp, nb, tmp + nb, d_total, st);
     if (vec) hipLaunchKernelGGL((scan_down_kernel<true, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);
     else hipLaunchKernelGGL((scan_down_kernel<false, InT, OutT>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const OutT*)tmp, (OutT*)nullptr);

@@ -26,7 +26,27 @@ struct HostTrieLevel {
     std::vector<u32> fc;
 };
 
+// A closed node of the unit depth (see StreamParser::unit_depth): what a merge that runs while the stream is still arriving needs
+// of the subtree that just ended -- its root's entry and, per deeper level, how many entries the stream held at that moment (the
+// subtree's entries of a level are the ones between the previous unit's mark and this one: levels are in path order).
+struct UnitMark {
+    u8 sym = 0;               // 0..3
+    u64 freq = 0;
+    u8 pl = 0;
+    u32 fc = 0;               // index of its first child inside level unit_depth + 1
+    std::vector<u64> upto;    // upto[k]: entries of level unit_depth + 1 + k at the close of the unit
+};
+
 struct StreamParser {
+    // Merging while receiving (dsm_server_*): the streams of one server all start with the same enforced path of unit_depth - 1
+    // symbols (metaenumerate's prefix, EnumerateQuery.cpp:240-290), so every level above unit_depth holds ONE node; the nodes of
+    // depth unit_depth are the units.  0 = off.  A stream that contradicts the hint (two nodes above the unit depth) is refused.
+    u32 unit_depth = 0;
+    std::vector<u8> unit_opened;     // symbols of the units opened so far, in stream order
+    std::vector<UnitMark> unit_closed;
+    std::vector<u8> chain_sym;       // symbols of the nodes above the unit depth (depth 1 ..), as far as the stream has them
+    struct ChainEnd { u64 freq = 0; u8 pl = 0; bool closed = false; };
+    std::vector<ChainEnd> chain;     // their entries once closed (they close when the stream ends)
     // Level l holds the entries [base[l], base[l] + L[l].freq.size()) of that level; earlier ones were taken by the consumer.
     std::vector<HostTrieLevel> L;
     std::vector<u64> base;
@@ -104,6 +124,14 @@ private:
                 par.pl[pi] |= (u8)(1u << k);
                 me.freq.push_back(0); me.pl.push_back(0); me.fc.push_back(0);
                 if (count(depth + 1) > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "stream: level too wide");
+                if (unit_depth) {
+                    if (depth + 1 < unit_depth) {
+                        if (count(depth + 1) > 1) return fail(DSM_E_FORMAT, "stream: two nodes above the unit depth (the prefix length given to the server is too long for this stream)");
+                        chain_sym.push_back((u8)k);
+                    } else if (depth + 1 == unit_depth) {
+                        unit_opened.push_back((u8)k);
+                    }
+                }
                 stack.push_back(count(depth + 1) - 1);
                 ++opened;
             } else {
@@ -128,6 +156,15 @@ private:
                 me.freq[mi] = f;
                 me.pl[mi] |= (u8)(code << 4);
                 mf = f > mf ? f : mf;
+                if (unit_depth && depth == unit_depth) {
+                    UnitMark um;
+                    um.sym = unit_opened.back(); um.freq = f; um.pl = me.pl[mi]; um.fc = me.fc[mi];
+                    for (size_t l = depth + 1; l < L.size(); ++l) um.upto.push_back(count(l));
+                    unit_closed.push_back(std::move(um));
+                } else if (unit_depth && depth < unit_depth) {
+                    if (chain.size() < depth) chain.resize(depth);
+                    chain[depth - 1].freq = f; chain[depth - 1].pl = me.pl[mi]; chain[depth - 1].closed = true;
+                }
                 stack.pop_back();
             }
         }

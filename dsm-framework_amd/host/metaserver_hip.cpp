@@ -1,9 +1,12 @@
 // metaserver_hip -- drop-in for the reference server (metaserver.cpp:488-815): same options, the expected sample names
 // on stdin, one TCP connection per sample carrying the reference wire protocol, reference-format tuples on stdout.
 // Unmodified reference clients (metaenumerate) can feed it.  A reader thread per connection hands the bytes to the library as
-// they arrive (dsm_trie_stream_feed: the reference's token rules and R checksums; what is decoded moves to the card in windows,
-// so the host never holds a stream), and when every stream has ended they are merged on the GPU (dsm_merge).
-//   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] < names.txt
+// they arrive (dsm_server_feed: the reference's token rules and R checksums; what is decoded moves to the card in windows, so the
+// host never holds a stream).  With --prefix-len K (the length of the prefix this server's clients enforce: one server per prefix,
+// wrapper-SLURM/example-server.sh:27-41) the streams are merged WHILE they arrive, as the reference's traverse() does
+// (metaserver.cpp:682-739): the subtree of every node of depth K + 1 is merged on the GPU and printed as soon as every connection
+// is past it, and leaves the card.  Without the option the merge starts when the last stream has ended.
+//   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] [--prefix-len K] < names.txt
 #include <getopt.h>
 #include <netinet/in.h>
 #include <sys/socket.h>
@@ -34,13 +37,14 @@ int main(int argc, char** argv) {
     if (argc <= 1) { std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1; }
     dsm_params p;
     dsm_params_default(&p);
-    int port = 54666, device = 0;  // metaserver.cpp:515
+    int port = 54666, device = 0, prefix_len = -1;  // metaserver.cpp:515
     bool verbose = false;
     static option long_options[] = {{"pmin", required_argument, 0, 'P'},     {"pmax", required_argument, 0, 258},
                                     {"port", required_argument, 0, 'p'},     {"mindepth", required_argument, 0, 'm'},
                                     {"emin", required_argument, 0, 'e'},     {"emax", required_argument, 0, 'E'},
                                     {"verbose", no_argument, 0, 'v'},        {"debug", no_argument, 0, 256},
-                                    {"device", required_argument, 0, 257},   {0, 0, 0, 0}};
+                                    {"device", required_argument, 0, 257},   {"prefix-len", required_argument, 0, 259},
+                                    {0, 0, 0, 0}};
     int c, oi = 0;
     while ((c = getopt_long(argc, argv, "P:p:m:e:E:F:T:vA", long_options, &oi)) != -1) {
         switch (c) {
@@ -53,6 +57,7 @@ int main(int argc, char** argv) {
             case 'v': verbose = true; break;
             case 256: case 'F': case 'T': case 'A': break;  // progress options of the reference: accepted, no effect
             case 257: device = atoi(optarg); break;
+            case 259: prefix_len = atoi(optarg); if (prefix_len < 0 || prefix_len > 32) { std::cerr << argv[0] << ": argument of --prefix-len must be 0..32" << std::endl; return 1; } break;
             default: std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1;
         }
     }
@@ -84,7 +89,8 @@ int main(int argc, char** argv) {
 
     std::vector<bool> seen(d, false);
     std::vector<std::thread> readers;
-    std::vector<dsm_trie*> tries(d, nullptr);
+    dsm_server* srv = nullptr;
+    if (dsm_server_create((int)d, device, prefix_len, &p, print_batch, nullptr, &srv)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
     std::string perr;
     std::mutex err_mu;
     size_t pending = d;
@@ -109,19 +115,17 @@ int main(int argc, char** argv) {
         seen[id] = true;
         --pending;
         if (verbose) std::cerr << "new connection id = " << id << ", name = " << name << " (" << pending << " pending)" << std::endl;
-        readers.emplace_back([fd, id, device, &tries, &perr, &err_mu] {
+        readers.emplace_back([fd, id, srv, &perr, &err_mu] {
             // decode while receiving: the streams of the samples are parsed side by side (the decoder is single-threaded per stream)
-            dsm_trie_stream* ts = nullptr;
-            int rc = dsm_trie_stream_begin(device, &ts);
+            int rc = 0;
             std::vector<uint8_t> buf(1 << 20);
             for (;;) {
                 ssize_t r = recv(fd, buf.data(), buf.size(), 0);
                 if (r <= 0) break;
-                if (!rc) rc = dsm_trie_stream_feed(ts, buf.data(), (size_t)r);  // (after an error the connection is drained, like a reader that gave up)
+                if (!rc) rc = dsm_server_feed(srv, id, buf.data(), (size_t)r);  // (after an error the connection is drained, like a reader that gave up)
             }
             close(fd);
-            if (!rc) { rc = dsm_trie_stream_end(ts, &tries[id]); ts = nullptr; }
-            if (ts) dsm_trie_stream_abort(ts);
+            if (!rc) rc = dsm_server_end(srv, id);
             if (rc) {
                 std::lock_guard<std::mutex> lk(err_mu);
                 if (perr.empty()) perr = std::string(dsm_last_error()) + " (reader " + std::to_string(id) + ")";
@@ -132,11 +136,16 @@ int main(int argc, char** argv) {
     close(sock);
     if (!perr.empty()) { std::cerr << "error: " << perr << std::endl; return 1; }
     dsm_stats st;
-    if (dsm_merge(tries.data(), (int)d, &p, print_batch, nullptr, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+    if (dsm_server_finish(srv, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
     fflush(stdout);
     if (verbose)
         std::cerr << "Number of paths: " << st.union_nodes << std::endl << "Number of reported paths: " << st.tuples << std::endl
                   << "Number of reported occs: " << st.pairs << std::endl;
-    for (auto* t : tries) dsm_trie_free(t);
+    if (verbose && prefix_len >= 0) {
+        uint64_t peak = 0;
+        const uint64_t units = dsm_server_units(srv, &peak);
+        std::cerr << "Subtrees merged while receiving: " << units << " (largest: " << peak << " nodes over all samples)" << std::endl;
+    }
+    dsm_server_destroy(srv);
     return 0;
 }

@@ -1,5 +1,7 @@
 // Host-side check of the server-side stream decoder (dsm-framework_amd/csrc/stream_parse.h) without a GPU:
 //   stream_parse_check <file> [piece]  ->  "ok nodes=<n> maxfreq=<f> levels=<l> sig=<hash of the level arrays>"  or  "error: <message>"
+//   stream_parse_check <file> <piece> <unit depth>  ->  the same plus " chain=<symbols> units=<symbol:nodes of the subtree,...>" from the marks
+//   the decoder leaves when a node of the unit depth closes (what dsm_server takes the subtrees out of the stream by)
 // The file holds a client stream WITHOUT the 'S' name '.' header (what dsm_trie_parse receives).
 #include <cstdio>
 #include <cstdlib>
@@ -8,7 +10,7 @@
 
 #include "../../dsm-framework_amd/csrc/stream_parse.h"
 
-static std::string g_err;
+static std::string g_err, g_units;
 namespace dsm {
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 }  // namespace dsm
@@ -32,6 +34,7 @@ int main(int argc, char** argv) {
         // the incremental decoder fed `piece` bytes at a time, with a consumer that takes every final entry away after each piece
         // (the way dsm_trie_stream moves them to the card): the collected levels must equal the one-shot parse
         dsm::StreamParser sp;
+        if (argc > 3) sp.unit_depth = (dsm::u32)atol(argv[3]);
         auto take = [&]() {
             if (L.size() < sp.L.size()) L.resize(sp.L.size());
             for (size_t l = 0; l < sp.L.size(); ++l) {
@@ -50,6 +53,20 @@ int main(int argc, char** argv) {
         if (!rc) take();
         nodes = sp.opened;
         maxfreq = sp.mf;
+        if (!rc && sp.unit_depth) {
+            g_units = " chain=";
+            for (auto c : sp.chain_sym) g_units += "ACGT"[c];
+            g_units += " units=";
+            std::vector<dsm::u64> from;
+            for (size_t q = 0; q < sp.unit_closed.size(); ++q) {
+                const dsm::UnitMark& um = sp.unit_closed[q];
+                if (from.size() < um.upto.size()) from.resize(um.upto.size(), 0);
+                dsm::u64 sz = 1;
+                for (size_t k = 0; k < um.upto.size(); ++k) { sz += um.upto[k] - from[k]; from[k] = um.upto[k]; }
+                g_units += (q ? "," : "") + std::string(1, "ACGT"[um.sym]) + ":" + std::to_string(sz) + ":" + std::to_string(um.freq);
+            }
+            if (sp.unit_closed.size() != sp.unit_opened.size()) g_units += " OPEN";
+        }
     }
     if (rc) { printf("error: %s\n", g_err.c_str()); return 1; }
     unsigned long long sig = 1469598103934665603ull;  // FNV-1a over (freq, pl, fc) of every node, level by level
@@ -59,6 +76,6 @@ int main(int argc, char** argv) {
         per_level_nodes += lv.freq.size();
         for (size_t i = 0; i < lv.freq.size(); ++i) { mixin(lv.freq[i]); mixin(lv.pl[i]); mixin(lv.fc[i]); }
     }
-    printf("ok nodes=%llu maxfreq=%llu levels=%zu stored=%llu sig=%llx\n", (unsigned long long)nodes, (unsigned long long)maxfreq, L.size(), per_level_nodes, sig);
+    printf("ok nodes=%llu maxfreq=%llu levels=%zu stored=%llu sig=%llx%s\n", (unsigned long long)nodes, (unsigned long long)maxfreq, L.size(), per_level_nodes, sig, g_units.c_str());
     return 0;
 }

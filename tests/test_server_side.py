@@ -112,6 +112,104 @@ def test_streams_fed_piece_by_piece_give_the_same_merge(golden, pydsm_mod):
                 pydsm_mod.Trie(bad, pieces=pieces)
 
 
+def _body(stream):
+    return stream[stream.index(b".") + 1:]
+
+
+def _feed_round_robin(srv, bodies, pieces):
+    pos = [0] * len(bodies)
+    k = 0
+    while any(pos[i] < len(b) for i, b in enumerate(bodies)):
+        for i, b in enumerate(bodies):
+            if pos[i] < len(b):
+                n = pieces[k % len(pieces)]
+                srv.feed(i, b[pos[i]:pos[i] + n])
+                pos[i] += n
+                k += 1
+    for i in range(len(bodies)):
+        srv.end(i)
+
+
+def test_server_merges_subtrees_while_the_streams_arrive(golden, pydsm_mod):
+    """dsm_server_* with the prefix length given (metaserver.cpp:682-739: the reference merges while it reads its sockets): the
+    subtree of every node one level below the enforced prefix is merged as soon as all connections are past it.  Output = the
+    reference server's, whatever the interleaving of the connections."""
+    import threading
+    m = golden.manifest["sets"]["toy3"]
+    names = m["names"]
+    for p in ["A", "C", "G", "T", "AC", "GT", "TTG"]:
+        bodies = [_body(golden.stream("toy3", n, p)) for n in names]
+        for cfg, args in m["server_cfgs"].items():
+            if p == "TTG" and cfg != "default":
+                continue
+            srv = pydsm_mod.Server(len(names), prefix_len=len(p), **server_args_to_kw(args))
+            _feed_round_robin(srv, bodies, [4096, 1000, 77])
+            got, st = srv.finish()
+            units, peak = srv.units()
+            srv.close()
+            assert got == golden.server_out("toy3", cfg, p), (cfg, p)
+            assert st.tuples == got.count(b"\n")
+            assert 1 <= units <= 4 and peak > 0
+    want = golden.server_out("toy3", "default", "A")
+    os.environ["DSM_TRIE_WINDOW"] = "64"   # windows of the levels go to the card (and leave it with a unit) all the time
+    try:
+        bodies = [_body(golden.stream("toy3", n, "A")) for n in names]
+        # one connection far ahead of the others, one far behind: a unit waits for the slowest stream
+        srv = pydsm_mod.Server(len(names), prefix_len=1, emax=2.0)
+        srv.feed(0, bodies[0]); srv.end(0)
+        for o in range(0, len(bodies[1]), 513):
+            srv.feed(1, bodies[1][o:o + 513])
+        srv.end(1)
+        for o in range(0, len(bodies[2]), 9999):
+            srv.feed(2, bodies[2][o:o + 9999])
+        srv.end(2)
+        got, _ = srv.finish()
+        assert srv.units()[0] == 4
+        srv.close()
+        assert got == want
+        # the connections' reader threads side by side (what metaserver_hip does)
+        srv = pydsm_mod.Server(len(names), prefix_len=1, emax=2.0)
+        def reader(i):
+            b = bodies[i]
+            for o in range(0, len(b), 1777 + 100 * i):
+                srv.feed(i, b[o:o + 1777 + 100 * i])
+            srv.end(i)
+        ths = [threading.Thread(target=reader, args=(i,)) for i in range(len(names))]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        got, _ = srv.finish()
+        srv.close()
+        assert got == want
+    finally:
+        del os.environ["DSM_TRIE_WINDOW"]
+    # a hint shorter than the prefix: one unit (the whole subtree), same output; no hint: merged by finish()
+    bodies = [_body(golden.stream("toy3", n, "AC")) for n in names]
+    for plen in (1, 0, None):
+        srv = pydsm_mod.Server(len(names), prefix_len=plen, emax=2.0)
+        _feed_round_robin(srv, bodies, [30000])
+        got, _ = srv.finish()
+        srv.close()
+        assert got == golden.server_out("toy3", "default", "AC"), plen
+    # a hint longer than the prefix: the stream is not a single path above the unit depth -> refused, not merged wrongly
+    srv = pydsm_mod.Server(len(names), prefix_len=3, emax=2.0)
+    with pytest.raises(pydsm_mod.DsmError):
+        _feed_round_robin(srv, bodies, [30000])
+        srv.finish()
+    srv.close()
+    # a sample whose stream is empty (prefix absent), and a sample that lacks one of the subtrees: equal to the merge of whole streams
+    t0 = pydsm_mod.Trie(golden.stream("toy3", names[0], "A"))
+    t1 = pydsm_mod.Trie(golden.stream("toy3", names[1], "AC"))   # only the subtree AC of A
+    empty = pydsm_mod.Trie(b"Stoy-9.")
+    want2, _ = pydsm_mod.merge([t0, empty, t1], pmin=1, emax=0.0)
+    srv = pydsm_mod.Server(3, prefix_len=1, pmin=1, emax=0.0)
+    _feed_round_robin(srv, [_body(golden.stream("toy3", names[0], "A")), b"", _body(golden.stream("toy3", names[1], "AC"))], [5000])
+    got2, _ = srv.finish()
+    srv.close()
+    assert got2 == want2 and got2
+    for t in (t0, t1, empty):
+        t.close()
+
+
 def test_corrupt_streams_are_rejected(golden, pydsm_mod):
     s = golden.stream("toy3", "toy-1", "C")
     body = s[s.index(b".") + 1:]
@@ -128,7 +226,8 @@ def test_corrupt_streams_are_rejected(golden, pydsm_mod):
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "metaenumerate")), reason="oracle/_ref/metaenumerate not present")
 def test_reference_clients_feed_our_server(golden, tmp_path):
     names = golden.manifest["sets"]["toy3"]["names"]
-    for prefix, cfg, sargs in [("G", "default", ["-E", "2.0"]), ("AC", "emin_m", ["-E", "1.4", "-e", "0.5", "-m", "8"])]:
+    for prefix, cfg, sargs in [("G", "default", ["-E", "2.0"]), ("AC", "emin_m", ["-E", "1.4", "-e", "0.5", "-m", "8"]),
+                               ("G", "default", ["-E", "2.0", "--prefix-len", "1"]), ("AC", "emin_m", ["-E", "1.4", "-e", "0.5", "-m", "8", "--prefix-len", "2"])]:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -82,3 +82,61 @@ def test_incremental_decode_equals_the_one_shot_parse(golden, exe, tmp_path):
         for piece in (1, 24, 4096):
             rc, out, _ = _run(exe, tmp_path, bad, piece)
             assert rc == 1 and out.startswith("error:"), (piece, out)
+
+
+def _tokens(body):
+    """An independent reading of the wire grammar (ClientSocket.h:12-46): yields ('open', sym) / ('close', freq)."""
+    i, depth = 0, 0
+    def varint():
+        nonlocal i
+        c = body[i]; i += 1
+        if c >= 0x80:
+            return c ^ 0x80
+        v = int.from_bytes(body[i:i + c], "little"); i += c
+        return v
+    while i < len(body):
+        if body[i:i + 1] == b"(":
+            depth += 1
+            yield ("open", chr(body[i + 1]), depth)
+            i += 2
+        else:
+            f = varint()
+            if depth <= 6:
+                assert body[i:i + 1] == b"R"; i += 1
+                varint()
+            i += 2
+            yield ("close", f, depth)
+            depth -= 1
+
+
+def test_unit_marks_of_the_decoder(golden, exe, tmp_path):
+    """dsm_server's unit of merging-while-receiving: when a node one level below the enforced prefix closes, the decoder notes how far
+    every deeper level has grown; the subtree sizes that follow from the marks equal an independent count over the token stream."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    for name, prefix in ((names[0], "A"), (names[1], "GT"), (names[2], "TTG")):
+        body = _body(golden.stream("toy3", name, prefix))
+        U = len(prefix) + 1
+        want, cur, size = [], None, 0
+        for kind, val, depth in _tokens(body):
+            if kind == "open":
+                if depth == U:
+                    cur, size = val, 0
+                if depth >= U:
+                    size += 1
+            elif depth == U:
+                want.append("%s:%d:%d" % (cur, size, val))
+        for piece in (1, 24, 1000, 1 << 20):
+            rc, out, err = _run_units(exe, tmp_path, body, piece, U)
+            assert rc == 0, (out, err)
+            fields = dict(kv.split("=") for kv in out.split()[1:])
+            assert fields["chain"] == prefix and fields["units"] == ",".join(want), (name, prefix, piece)
+        # a hint that is too long for the stream is refused
+        rc, out, _ = _run_units(exe, tmp_path, body, 4096, U + 1)
+        assert rc == 1 and "unit depth" in out
+
+
+def _run_units(exe, tmp_path, body, piece, unit_depth):
+    p = tmp_path / "s.bin"
+    p.write_bytes(body)
+    r = subprocess.run([exe, str(p), str(piece), str(unit_depth)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout.decode().strip(), r.stderr.decode()
