@@ -17,6 +17,7 @@
 // of a prefix from subtree aggregates over the retained levels (prefix sums, no sorting).
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -27,6 +28,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <thread>
 #include <type_traits>
 
@@ -231,6 +233,10 @@ struct ExpandArgs {
     // (formats are launch-time choices) or the level does not fit -- the host then sees the same words and launches again.
     const u32* dyn;    // null: F, nbp and the formats above are final
     u32 dyn_expect, dyn_mask, fcap;
+#ifdef DSM_CLOCK_PROBE
+    u32 probe_slot;    // counter shard that collects this launch's wave times
+    unsigned long long* probe_buf;   // per wave of ONE chosen launch: start, end, hardware ids
+#endif
 };
 
 __device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
@@ -615,23 +621,24 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     const int lane = threadIdx.x & 63;
     const u32 nwaves = gridDim.x * 4;
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 t0 = gw;
     const u32 ntile = (a.F + 63) >> 6;
     ExpandAcc acc;
 #ifdef DSM_CLOCK_PROBE
     const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
-    // prologue of the pipeline: heads of the wave's first tile, handles of its second
-    u32 rn = DEAD;
     {
+        // prologue of the pipeline: heads of the wave's first tile, handles of its second
+        u32 rn = DEAD;
         u32 r0 = DEAD;
-        const u32 i0 = gw * 64 + lane, i1 = (gw + nwaves) * 64 + lane;
-        if (gw < ntile && i0 < a.F) r0 = rp[i0];
-        if (gw + nwaves < ntile && i1 < a.F) rn = rp[i1];
+        const u32 i0 = t0 * 64 + lane, i1 = (t0 + nwaves) * 64 + lane;
+        if (t0 < ntile && i0 < a.F) r0 = rp[i0];
+        if (t0 + nwaves < ntile && i1 < a.F) rn = rp[i1];
         SelfState ss;
         if (SELF) {  // r0, rn hold slots here: handles of the first tile now, the deeper stages primed
-            const u32 i2 = (gw + 2 * nwaves) * 64 + lane;
+            const u32 i2 = (t0 + 2 * nwaves) * 64 + lane;
             ss.s1 = rn;
-            if (gw + 2 * nwaves < ntile && i2 < a.F) ss.s2 = rp[i2];
+            if (t0 + 2 * nwaves < ntile && i2 < a.F) ss.s2 = rp[i2];
             const u64 p0 = pplane[self_plane_index(r0)];
             ss.pn = pplane[self_plane_index(ss.s1)];
             r0 = self_handle(r0, p0, a.seg);
@@ -639,7 +646,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         RecHead<P, INC> hA, hB;
         load_head<P>(rec, a.cap, r0, hA);
         // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
-        for (u32 t = gw; t < ntile; t += 2 * nwaves) {
+        for (u32 t = t0; t < ntile; t += 2 * nwaves) {
             expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, pplane, &ss);
             if (t + nwaves < ntile)
                 expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss);
@@ -649,6 +656,17 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
         atomicAdd((unsigned long long*)&counters[6], (unsigned long long)(__builtin_readcyclecounter() - probe_c0));
         atomicAdd((unsigned long long*)&counters[7], (unsigned long long)(wall_clock64() - probe_r0));
+    }
+    if (lane == 0 && t0 < ntile) {  // every wave with tiles: its start and end (100 MHz ticks): earliest, latest and sum of both, per launch (three shards)
+        const unsigned long long e1 = (unsigned long long)wall_clock64(), s1 = (unsigned long long)probe_r0;
+        unsigned long long* q = (unsigned long long*)&counters[(size_t)a.probe_slot * 8];
+        atomicMax(q + 6, ~s1); atomicMax(q + 7, s1);
+        atomicMax(q + 8 + 6, ~e1); atomicMax(q + 8 + 7, e1);
+        atomicAdd(q + 16 + 6, s1 & 0xFFFFFFFFull); atomicAdd(q + 16 + 7, e1 & 0xFFFFFFFFull);
+        if (a.probe_buf && gw < 8192) {
+            const u32 hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+            a.probe_buf[(size_t)gw * 3] = s1; a.probe_buf[(size_t)gw * 3 + 1] = e1; a.probe_buf[(size_t)gw * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+        }
     }
 #endif
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
@@ -2513,6 +2531,10 @@ class Engine {
     u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_wsum = nullptr, *cand_wscan = nullptr, *scan_tmp64 = nullptr;  // per wave of 64 nodes: candidates | pairs << 32, and their scan
     u64* d_counters = nullptr;
+#ifdef DSM_CLOCK_PROBE
+    unsigned long long* d_probe = nullptr;
+    u32 probe_F = 0;
+#endif
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, [8..8+MAX_LOCAL) record allocations, [300..] u64 totals
@@ -2944,6 +2966,12 @@ class Engine {
                 const bool ent_ok = !(prm.emax > 0 && (0.0 < prm.emin - ENT_MARGIN || 0.0 > prm.emax + ENT_MARGIN));
                 if (emit_level && depth >= prm.mindepth && prm.pmin <= 1 && ent_ok) ea.symbol_phase |= 4u;
             }
+#ifdef DSM_CLOCK_PROBE
+            ea.probe_slot = 1u + 3u * ((u32)(nev / 2) % (u32)((COUNTER_SHARDS - 4) / 3));
+            if (!d_probe) { DSM_HIP(hipMalloc((void**)&d_probe, 8192 * 3 * sizeof(u64))); }
+            ea.probe_buf = (nev / 2 == 50) ? d_probe : nullptr;
+            if (ea.probe_buf) { DSM_HIP(hipMemsetAsync(d_probe, 0, 8192 * 3 * sizeof(u64), st)); probe_F = F ? F : (u32)(Fmax / 4); }
+#endif
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
@@ -3377,7 +3405,68 @@ class Engine {
             for (int k = 0; k < COUNTER_SHARDS; ++k)
                 for (int c = 0; c < NCOUNTERS; ++c) hc[c] += sh[(size_t)k * 8 + c];
 #ifdef DSM_CLOCK_PROBE
-            if (sh[7]) fprintf(stderr, "clock probe: %.1f MHz over %.2f ms of LF-step sweeps\n", (double)sh[6] / (double)sh[7] * 100.0, (double)sh[7] * 1e-5);
+            if (sh[7]) {
+                double dur = 0, ramp = 0, tail = 0, meanbusy = 0;
+                int nl = 0;
+                const double W = (double)expand_blocks * 4;
+                for (int k = 1; k + 2 < COUNTER_SHARDS; k += 3) {
+                    const u64 s0 = ~sh[(size_t)k * 8 + 6], s9 = sh[(size_t)k * 8 + 7], e0 = ~sh[(size_t)(k + 1) * 8 + 6], e9 = sh[(size_t)(k + 1) * 8 + 7];
+                    if (!s9 || e9 - s0 < 5000) continue;   // launches of 50 us or more
+                    const double ms = (double)sh[(size_t)(k + 2) * 8 + 6] / W, me = (double)sh[(size_t)(k + 2) * 8 + 7] / W;  // (low 32 bits of the ticks, summed)
+                    dur += (double)(e9 - s0); ramp += (double)(s9 - s0); tail += (double)(e9 - e0); meanbusy += me - ms; ++nl;
+                }
+                if (d_probe && probe_F) {
+                    std::vector<u64> pb(8192 * 3);
+                    DSM_HIP(hipMemcpy(pb.data(), d_probe, pb.size() * sizeof(u64), hipMemcpyDeviceToHost));
+                    u64 t0 = ~0ull, t9 = 0;
+                    for (int w = 0; w < 8192; ++w) if (pb[w * 3 + 1]) { t0 = pb[w * 3] < t0 ? pb[w * 3] : t0; t9 = pb[w * 3 + 1] > t9 ? pb[w * 3 + 1] : t9; }
+                    double byx[16] = {0}, byse[8] = {0}; int nx[16] = {0}, nse[8] = {0};
+                    double bysimd[4] = {0}; int nsimd[4] = {0}; int nmis = 0;
+                    std::map<u32, std::pair<double, int>> bycu;
+                    for (int w = 0; w < 8192; ++w) {
+                        if (!pb[w * 3 + 1]) continue;
+                        const double e = (double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0);
+                        const u32 hw = (u32)pb[w * 3 + 2], xcc = (u32)(pb[w * 3 + 2] >> 32) & 15u;
+                        byx[xcc] += e; ++nx[xcc];
+                        if (xcc != (u32)((w >> 2) & 7)) ++nmis;
+                        const u32 se = (hw >> 13) & 7u, cu = (hw >> 8) & 15u, simd = (hw >> 4) & 3u;
+                        byse[se] += e; ++nse[se]; bysimd[simd] += e; ++nsimd[simd];
+                        auto& q = bycu[(xcc << 8) | (se << 4) | cu]; q.first += e; q.second++;
+                    }
+                    {   // spread of the wave ends inside every XCC
+                        std::vector<double> ends[16];
+                        for (int w = 0; w < 8192; ++w) if (pb[w * 3 + 1]) ends[(pb[w * 3 + 2] >> 32) & 15u].push_back((double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0));
+                        fprintf(stderr, "probe launch F=%u: wave ends inside an XCC (min / 10%% / median / 90%% / max):", probe_F);
+                        for (int k = 0; k < 16; ++k) {
+                            if (ends[k].empty()) continue;
+                            std::sort(ends[k].begin(), ends[k].end());
+                            const size_t n = ends[k].size();
+                            fprintf(stderr, " %d: %.2f %.2f %.2f %.2f %.2f;", k, ends[k][0], ends[k][n / 10], ends[k][n / 2], ends[k][n * 9 / 10], ends[k][n - 1]);
+                        }
+                        fprintf(stderr, "\n");
+                    }
+                    {   // by dispatch order: blocks in sixteenths of the grid
+                        double sum[16] = {0}; int n[16] = {0};
+                        const int per = (int)(expand_blocks * 4 / 16);
+                        for (int w = 0; w < 8192 && per; ++w) if (pb[w * 3 + 1]) { const int q = w / per < 16 ? w / per : 15; sum[q] += (double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0); ++n[q]; }
+                        fprintf(stderr, "probe launch F=%u: mean relative end by sixteenth of the grid (dispatch order):", probe_F);
+                        for (int q = 0; q < 16; ++q) if (n[q]) fprintf(stderr, " %.3f", sum[q] / n[q]);
+                        fprintf(stderr, "\n");
+                    }
+                    fprintf(stderr, "probe launch F=%u: %.1f us; mean relative end by XCC:", probe_F, (double)(t9 - t0) * 0.01);
+                    for (int k = 0; k < 16; ++k) if (nx[k]) fprintf(stderr, " %d:%.3f(%d)", k, byx[k] / nx[k], nx[k]);
+                    fprintf(stderr, "; by SE:");
+                    for (int k = 0; k < 8; ++k) if (nse[k]) fprintf(stderr, " %d:%.3f(%d)", k, byse[k] / nse[k], nse[k]);
+                    fprintf(stderr, "; by SIMD:");
+                    for (int k = 0; k < 4; ++k) if (nsimd[k]) fprintf(stderr, " %d:%.3f(%d)", k, bysimd[k] / nsimd[k], nsimd[k]);
+                    double lo = 2, hi = 0; int ncu = 0, minw = 1 << 30, maxw = 0;
+                    for (auto& kv : bycu) { const double m = kv.second.first / kv.second.second; lo = m < lo ? m : lo; hi = m > hi ? m : hi; ++ncu; minw = kv.second.second < minw ? kv.second.second : minw; maxw = kv.second.second > maxw ? kv.second.second : maxw; }
+                    fprintf(stderr, "; %d CUs: mean relative end %.3f .. %.3f, waves per CU %d .. %d; waves whose XCC is not block %% 8: %d\n", ncu, lo, hi, minw, maxw, nmis);
+                    probe_F = 0;
+                }
+                fprintf(stderr, "clock probe: %.1f MHz; %d launches >= 50 us: duration %.2f ms, first-to-last wave start %.2f ms, first-to-last wave end %.2f ms, mean wave busy %.2f ms\n",
+                        (double)sh[6] / (double)sh[7] * 100.0, nl, dur * 1e-5, ramp * 1e-5, tail * 1e-5, meanbusy * 1e-5);
+            }
 #endif
         }
         stats.reported += hc[0];
@@ -4217,30 +4306,25 @@ struct dsm_server {
         }
         return 0;
     }
-    // a trie of the nodes above the unit depth and, at the unit depth, the given roots: what a shallow pass needs.  `final`: the
-    // path nodes carry their own frequencies and left chars (they have closed), otherwise place holders (nothing prints them)
-    int hollow(Stream& st, int upto_sym, bool final, dsm_trie** out) {
+    // a trie of the levels down to the unit depth as the stream has them now: the enforced path, the nodes between it and the units,
+    // the unit roots.  Nodes that are still open carry a place holder for their frequency (nothing prints them).  Caller holds st.mu
+    int hollow(Stream& st, dsm_trie** out) {
         using namespace dsm;
         std::vector<u64> f; std::vector<u8> pl; std::vector<u32> fc;
         std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
         t->device = device;
-        const size_t clen = st.sp.chain_sym.size();  // nodes of depth 1 .. clen exist on the path (clen <= K)
-        std::vector<const UnitMark*> roots;
-        for (const UnitMark& um : st.sp.unit_closed) if ((int)um.sym <= upto_sym) roots.push_back(&um);
-        u32 rootmask = 0;
-        for (const UnitMark* um : roots) rootmask |= 1u << um->sym;
-        for (size_t l = 0; l <= clen; ++l) {  // level l: the path node of depth l (0 = the root)
+        const size_t nl = st.sp.L.size() < (size_t)U + 1 ? st.sp.L.size() : (size_t)U + 1;
+        for (size_t l = 0; l < nl; ++l) {
+            const HostTrieLevel& h = st.sp.L[l];   // (these levels are never taken away from the host: a handful of entries)
+            if (h.freq.empty()) break;
             t->level_off.push_back(f.size());
-            const bool end = l == (size_t)K;   // its children are the units
-            u32 kids = end ? rootmask : (l < clen ? 1u << st.sp.chain_sym[l] : 0u);
-            u64 fr = l ? 1 : 0;
-            u32 code = 0;
-            if (final && l >= 1 && l - 1 < st.sp.chain.size() && st.sp.chain[l - 1].closed) { fr = st.sp.chain[l - 1].freq; code = st.sp.chain[l - 1].pl >> 4; }
-            f.push_back(fr); pl.push_back((u8)(kids | (code << 4))); fc.push_back(0);
-        }
-        if (clen == (size_t)K && !roots.empty()) {
-            t->level_off.push_back(f.size());
-            for (const UnitMark* um : roots) { f.push_back(um->freq); pl.push_back(um->pl); fc.push_back(0); if (um->freq > t->maxfreq) t->maxfreq = um->freq; }
+            for (size_t i = 0; i < h.freq.size(); ++i) {
+                const bool open = !st.sp.finished && l < st.sp.stack.size() && st.sp.stack[l] == st.sp.base[l] + i;
+                f.push_back(l == 0 ? 0 : (open || h.freq[i] == 0 ? 1 : h.freq[i]));
+                pl.push_back(h.pl[i]);
+                fc.push_back(h.fc[i]);
+                if (h.freq[i] > t->maxfreq) t->maxfreq = h.freq[i];
+            }
         }
         t->level_off.push_back(f.size());
         t->nodes = f.size();
@@ -4253,28 +4337,62 @@ struct dsm_server {
         *out = t.release();
         return 0;
     }
-    // the next unit of the stream leaves its windows as a compact trie: path, root, and its range of every deeper level.  Caller holds st.mu
-    int take_unit(Stream& st, dsm_trie** out) {
+    // the same cut down to the single path towards `path` (no siblings): the top of a sample that lacks a unit
+    int path_only(Stream& st, const std::vector<dsm::u8>& path, dsm_trie** out) {
         using namespace dsm;
-        const UnitMark& um = st.sp.unit_closed[st.taken];
+        std::vector<u64> f; std::vector<u8> pl; std::vector<u32> fc;
+        std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
+        t->device = device;
+        // follow the path as far as the stream has it
+        size_t idx = 0;
+        for (size_t l = 0; l < st.sp.L.size() && l <= (size_t)K + path.size(); ++l) {
+            const HostTrieLevel& h = st.sp.L[l];
+            if (h.freq.empty() || idx >= h.freq.size()) break;
+            t->level_off.push_back(f.size());
+            int next = -1;  // symbol of the next node of the path
+            if (l < (size_t)K) next = l < st.sp.chain_sym.size() ? (int)st.sp.chain_sym[l] : -1;
+            else if (l - (size_t)K + 1 < path.size()) next = (int)path[l - (size_t)K];   // (the unit itself is not part of it)
+            const u32 kids = h.pl[idx] & 15u;
+            const bool has = next >= 0 && ((kids >> next) & 1u);
+            f.push_back(l ? 1 : 0); pl.push_back((u8)(has ? 1u << next : 0u)); fc.push_back(0);
+            if (!has) break;
+            idx = (size_t)h.fc[idx] + (size_t)__builtin_popcount(kids & ((1u << next) - 1u)) - (size_t)st.sp.base[l + 1];
+        }
+        if (t->level_off.empty()) { t->level_off.push_back(0); f.push_back(0); pl.push_back(0); fc.push_back(0); }
+        t->level_off.push_back(f.size());
+        t->nodes = f.size();
+        DSM_HIP(hipMalloc((void**)&t->d_freq, f.size() * sizeof(u64)));
+        DSM_HIP(hipMalloc((void**)&t->d_pl, f.size()));
+        DSM_HIP(hipMalloc((void**)&t->d_fc, f.size() * sizeof(u32)));
+        DSM_HIP(hipMemcpy(t->d_freq, f.data(), f.size() * sizeof(u64), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_pl, pl.data(), f.size(), hipMemcpyHostToDevice));
+        DSM_HIP(hipMemcpy(t->d_fc, fc.data(), f.size() * sizeof(u32), hipMemcpyHostToDevice));
+        *out = t.release();
+        return 0;
+    }
+    // the unit of the stream's next event leaves its windows as a compact trie: path, root, and its range of every deeper level.  Caller holds st.mu
+    int take_unit(Stream& st, const dsm::UnitEvent& ev, dsm_trie** out) {
+        using namespace dsm;
         if (int r = upload(st, true)) return r;
         std::unique_ptr<dsm_trie, void (*)(dsm_trie*)> t(new dsm_trie(), dsm_trie_free);
         t->device = device;
-        const size_t nl = um.upto.size();  // levels below the unit depth that existed when the unit closed
+        const size_t nl = ev.upto.size();  // levels below the unit depth that existed when the unit closed
         if (st.from.size() < nl) st.from.resize(nl, 0);
         u64 tot = (u64)U + 1;
         for (size_t k = 0; k < nl; ++k) {
-            if (um.upto[k] < st.from[k]) return fail(DSM_E_HIP, "dsm_server: unit marks out of order");
-            tot += um.upto[k] - st.from[k];
+            if (ev.upto[k] < st.from[k]) return fail(DSM_E_HIP, "dsm_server: unit marks out of order");
+            tot += ev.upto[k] - st.from[k];
         }
         DSM_HIP(hipMalloc((void**)&t->d_freq, tot * sizeof(u64)));
         DSM_HIP(hipMalloc((void**)&t->d_pl, tot));
         DSM_HIP(hipMalloc((void**)&t->d_fc, tot * sizeof(u32)));
+        const HostTrieLevel& hu = st.sp.L[U];
+        const size_t ri = (size_t)(ev.index - st.sp.base[U]);
         std::vector<u64> f; std::vector<u8> pl; std::vector<u32> fc;
         for (u32 l = 0; l <= U; ++l) {
             t->level_off.push_back(l);
-            if (l == U) { f.push_back(um.freq); pl.push_back(um.pl); fc.push_back(0); }
-            else { f.push_back(l ? 1 : 0); pl.push_back((u8)(1u << (l + 1 == U ? um.sym : st.sp.chain_sym[l]))); fc.push_back(0); }
+            if (l == U) { f.push_back(hu.freq[ri]); pl.push_back(hu.pl[ri]); fc.push_back(0); }
+            else { f.push_back(l ? 1 : 0); pl.push_back((u8)(1u << (l < (u32)K ? st.sp.chain_sym[l] : ev.path[l - (u32)K]))); fc.push_back(0); }
         }
         DSM_HIP(hipMemcpy(t->d_freq, f.data(), f.size() * sizeof(u64), hipMemcpyHostToDevice));
         DSM_HIP(hipMemcpy(t->d_pl, pl.data(), f.size(), hipMemcpyHostToDevice));
@@ -4282,7 +4400,7 @@ struct dsm_server {
         u64 o = (u64)U + 1;
         for (size_t k = 0; k < nl; ++k) {
             const size_t l = (size_t)U + 1 + k;
-            const u64 a = st.from[k], b = um.upto[k], cnt = b - a;
+            const u64 a = st.from[k], b = ev.upto[k], cnt = b - a;
             if (cnt == 0) break;  // (a level without entries of this unit: none deeper either)
             t->level_off.push_back(o);
             DevLevel& v = st.dl[l];
@@ -4312,36 +4430,59 @@ struct dsm_server {
         t->level_off.push_back(o);
         t->nodes = o;
         t->maxfreq = st.sp.mf;
-        for (size_t k = 0; k < nl; ++k) st.from[k] = um.upto[k];
-        ++st.taken;
+        for (size_t k = 0; k < nl; ++k) st.from[k] = ev.upto[k];
         *out = t.release();
         return 0;
     }
-    // is the unit with symbol c final in the stream?  (caller holds st.mu)
-    static bool past(const Stream& st, int c) {
-        if (st.ended) return true;
-        for (const dsm::UnitMark& um : st.sp.unit_closed) if ((int)um.sym >= c) return true;
-        return !st.sp.unit_opened.empty() && (int)st.sp.unit_opened.back() > c;
-    }
-    void add_stats(const dsm_stats& a, dsm::u64 path_nodes) {
+    void add_stats(const dsm_stats& a, dsm::u64 nodes) {
         stats.tuples += a.tuples; stats.pairs += a.pairs; stats.candidates += a.candidates;
-        stats.union_nodes += a.union_nodes >= path_nodes ? a.union_nodes - path_nodes : 0;
+        stats.union_nodes += nodes;
         stats.levels += a.levels; stats.device_ms += a.device_ms; stats.host_ms += a.host_ms; stats.splits += a.splits;
         if (a.max_frontier > stats.max_frontier) stats.max_frontier = a.max_frontier;
         stats.pair_order_exact = a.pair_order_exact;
     }
-    std::string path_text(const Stream& st) const {
-        std::string p;
-        for (dsm::u8 c : st.sp.chain_sym) p += "ACGT"[c];
-        return p;
+    std::string text_of(const std::vector<dsm::u8>& p) const {
+        std::string t;
+        for (dsm::u8 c : p) t += "ACGT"[c];
+        return t;
     }
-    // one unit, every stream past it: out of the windows, the order of its root from a shallow pass, merge, print
-    int merge_unit(int c) {
+    // Reader-set iteration order of a node below the enforced path (metaserver.cpp:322-339): it follows from its parent's order and
+    // the reader sets of its EARLIER siblings, all final once every stream is past the node -- a shallow pass over the parent's
+    // children with the parent's order as its seed, remembered (a node's order never changes afterwards).
+    std::map<std::vector<dsm::u8>, std::vector<dsm::u16>> orders;
+    int order_of(const std::vector<dsm::u8>& path, dsm_trie* const* hol, bool wide, const std::string& chain, std::vector<dsm::u16>* out) {
+        using namespace dsm;
+        auto f = orders.find(path);
+        if (f != orders.end()) { *out = f->second; return 0; }
+        const std::vector<u8> parent(path.begin(), path.end() - 1);
+        ServerOrder cap, seed;
+        cap.depth = (u32)K + (u32)path.size();
+        const ServerOrder* sp = nullptr;
+        if (!parent.empty()) {
+            std::vector<u16> po;
+            if (int r = order_of(parent, hol, wide, chain, &po)) return r;
+            seed.depth = (u32)K + (u32)parent.size();
+            seed.ord.push_back(po);
+            sp = &seed;
+        }
+        if (int r = server_run(wide, hol, d, prm, chain + text_of(parent), sink, ctx, false, 1, ~0u, cap.depth, sp, &cap, nullptr)) return r;
+        size_t q = 0;
+        while (q < cap.sym.size() && cap.sym[q] != (u32)path.back()) ++q;
+        if (q == cap.sym.size()) return fail(DSM_E_HIP, "dsm_server: the shallow pass did not find the node " + chain + text_of(path));
+        orders[path] = cap.ord[q];
+        *out = cap.ord[q];
+        return 0;
+    }
+    // One event -- a unit, or a node between the enforced path and the units -- that every stream is past.  A unit leaves the
+    // windows, its root's reader-set order comes from a shallow pass, it is merged and printed; a node between is printed by a
+    // run over the top of the streams that shows it its children and emits its depth only.
+    int merge_event(const std::vector<dsm::u8>& path) {
         using namespace dsm;
         DSM_HIP(hipSetDevice(device));
+        const bool is_unit = path.size() == (size_t)(U - (u32)K);
         std::vector<dsm_trie*> unit(d, nullptr), hol(d, nullptr);
         auto cleanup = [&] { for (auto* t : unit) if (t) dsm_trie_free(t); for (auto* t : hol) if (t) dsm_trie_free(t); };
-        std::string path;
+        std::string chain;
         bool wide = prm.wide != 0;
         u64 nodes = 0;
         int r = 0;
@@ -4349,87 +4490,92 @@ struct dsm_server {
             Stream& st = *s[k];
             std::lock_guard<std::mutex> lk(st.mu);
             if (st.sp.chain_sym.size() == (size_t)K) {
-                const std::string mine = path_text(st);
-                if (path.empty()) path = mine;
-                else if (path != mine) r = fail(DSM_E_FORMAT, "dsm_server: the connections enforce different prefixes (" + path + " / " + mine + ")");
+                const std::string mine = text_of(st.sp.chain_sym);
+                if (chain.empty()) chain = mine;
+                else if (chain != mine) r = fail(DSM_E_FORMAT, "dsm_server: the connections enforce different prefixes (" + chain + " / " + mine + ")");
             }
             if (r) break;
             if (st.sp.mf >= 0xFFFFFFF0ull) wide = true;
-            const bool has = st.taken < st.sp.unit_closed.size() && (int)st.sp.unit_closed[st.taken].sym == c;
-            r = hollow(st, c, false, &hol[k]);
-            if (!r) r = has ? take_unit(st, &unit[k]) : hollow(st, c - 1, false, &unit[k]);  // (a sample without the unit: its path, no root)
-            if (!r) nodes += unit[k]->nodes;
+            const bool has = st.taken < st.sp.events.size() && st.sp.events[st.taken].path == path;
+            r = hollow(st, &hol[k]);
+            if (!r && is_unit) {
+                r = has ? take_unit(st, st.sp.events[st.taken], &unit[k]) : path_only(st, path, &unit[k]);
+                if (!r) nodes += unit[k]->nodes;
+            }
+            if (!r && has) ++st.taken;
         }
         if (r) { cleanup(); return r; }
-        ServerOrder cap, seed;
-        cap.depth = U;
-        r = server_run(wide, hol.data(), d, prm, path, sink, ctx, false, 1, ~0u, U, nullptr, &cap, nullptr);
-        if (!r) {
-            size_t q = 0;
-            while (q < cap.sym.size() && (int)cap.sym[q] != c) ++q;
-            if (q == cap.sym.size()) r = fail(DSM_E_HIP, "dsm_server: the shallow pass did not find the unit");
-            else { seed.depth = U; seed.ord.push_back(cap.ord[q]); }
-        }
+        const std::string full = chain + text_of(path);
+        const u32 depth = (u32)full.size();
         dsm_stats a;
         memset(&a, 0, sizeof a);
-        if (!r) r = server_run(wide, unit.data(), d, prm, path + "ACGT"[c], sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);
-        if (!r) { add_stats(a, (u64)K); ++units_merged; if (nodes > peak_unit_nodes) peak_unit_nodes = nodes; }
+        ServerOrder seed;
+        seed.depth = depth;
+        seed.ord.emplace_back();
+        r = order_of(path, hol.data(), wide, chain, &seed.ord[0]);
+        if (!r && is_unit) {
+            r = server_run(wide, unit.data(), d, prm, full, sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);
+            if (!r) { add_stats(a, a.union_nodes >= (u64)(U - 1) ? a.union_nodes - (u64)(U - 1) : 0); ++units_merged; if (nodes > peak_unit_nodes) peak_unit_nodes = nodes; }
+        } else if (!r) {
+            r = server_run(wide, hol.data(), d, prm, full, sink, ctx, true, depth, depth, depth + 1, &seed, nullptr, &a);
+            if (!r) add_stats(a, 1);
+        }
         cleanup();
         return r;
     }
-    // the nodes of the enforced path, after every unit and every stream's end
+    // the nodes of the enforced path, after every event and every stream's end
     int merge_path() {
         using namespace dsm;
         if (K < 1) return 0;
         DSM_HIP(hipSetDevice(device));
         std::vector<dsm_trie*> hol(d, nullptr);
-        std::string path;
+        std::string chain;
         bool wide = prm.wide != 0;
         int r = 0;
-        u64 roots = 0;
         for (int k = 0; k < d && !r; ++k) {
             Stream& st = *s[k];
             std::lock_guard<std::mutex> lk(st.mu);
-            if (st.sp.chain_sym.size() == (size_t)K && path.empty()) path = path_text(st);
+            if (st.sp.chain_sym.size() == (size_t)K && chain.empty()) chain = text_of(st.sp.chain_sym);
             if (st.sp.mf >= 0xFFFFFFF0ull) wide = true;
-            r = hollow(st, 3, true, &hol[k]);
+            r = hollow(st, &hol[k]);
         }
-        for (int k = 0; k < d; ++k) roots += s[k]->sp.unit_closed.size() ? 1 : 0;
         dsm_stats a;
         memset(&a, 0, sizeof a);
-        if (!r && !path.empty()) {
-            r = server_run(wide, hol.data(), d, prm, path, sink, ctx, true, 1, (u32)K, U, nullptr, nullptr, &a);
-            if (!r) {  // (the pass walked the path and the unit roots: the roots were counted with their units)
-                const u64 below = a.union_nodes >= (u64)K ? a.union_nodes - (u64)K : 0;
-                add_stats(a, below);
-            }
+        if (!r && !chain.empty()) {
+            r = server_run(wide, hol.data(), d, prm, chain, sink, ctx, true, 1, (u32)K, (u32)K + 1, nullptr, nullptr, &a);
+            if (!r) add_stats(a, (u64)K);
         }
         for (auto* t : hol) if (t) dsm_trie_free(t);
         return r;
     }
     void merger_main() {
-        int next = 0;  // units with a smaller symbol have been merged
         for (;;) {
-            int c = -1;
-            bool all_ended = true;
+            std::vector<dsm::u8> ev;
+            bool have = false, all_ended = true;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     if (quit || rc) return;
-                    // the smallest symbol, not merged yet, that some stream has opened as a unit -- ready when every stream is past it
-                    c = -1;
+                    // the first event, in the post-order of the union trie, among the streams' next ones -- ready when no stream can still
+                    // produce it or one before it
+                    have = false;
                     all_ended = true;
-                    bool ready = true;
                     for (int k = 0; k < d; ++k) {
                         Stream& st = *s[k];
                         std::lock_guard<std::mutex> sl(st.mu);
                         all_ended = all_ended && st.ended;
-                        for (dsm::u8 o : st.sp.unit_opened) if ((int)o >= next && (c < 0 || (int)o < c)) c = (int)o;
+                        if (st.taken < st.sp.events.size()) {
+                            const std::vector<dsm::u8>& p = st.sp.events[st.taken].path;
+                            if (!have || dsm::post_before(p, ev)) { ev = p; have = true; }
+                        }
                     }
-                    if (c >= 0) {
+                    if (have) {
+                        bool ready = true;
                         for (int k = 0; k < d && ready; ++k) {
-                            std::lock_guard<std::mutex> sl(s[k]->mu);
-                            ready = past(*s[k], c);
+                            Stream& st = *s[k];
+                            std::lock_guard<std::mutex> sl(st.mu);
+                            const bool mine = st.taken < st.sp.events.size() && st.sp.events[st.taken].path == ev;
+                            ready = mine || st.ended || !st.sp.may_produce(ev);
                         }
                         if (ready) break;
                     } else if (all_ended) {
@@ -4438,26 +4584,24 @@ struct dsm_server {
                     cv.wait(lk);
                 }
             }
-            int r;
-            if (c >= 0) { r = merge_unit(c); next = c + 1; }
-            else r = merge_path();
+            const int r = have ? merge_event(ev) : merge_path();
             std::lock_guard<std::mutex> lk(mu);
             if (r) { rc = r; err = dsm_last_error(); cv.notify_all(); return; }
-            if (c < 0) { done = true; cv.notify_all(); return; }
+            if (!have) { done = true; cv.notify_all(); return; }
         }
     }
 };
 
-int dsm_server_create(int nsamples, int device, int prefix_len, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_server** out) {
+int dsm_server_create(int nsamples, int device, int prefix_len, int unit_extra, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_server** out) {
     if (!out || !p || nsamples <= 0 || !sink) return fail(DSM_E_INVAL, "dsm_server_create: bad arguments");
     *out = nullptr;
     if (nsamples > 273) return fail(DSM_E_INVAL, "too many samples (MAX_READERS 273, metaserver.cpp:19)");
-    if (prefix_len > 32) return fail(DSM_E_INVAL, "dsm_server_create: prefix_len > 32");
+    if (prefix_len > 32 || unit_extra < 0 || unit_extra > 4) return fail(DSM_E_INVAL, "dsm_server_create: prefix_len > 32 or unit_extra outside 0..4");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DSM_E_NODEV, "dsm_server_create: no HIP device");
     if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_server_create: bad device ordinal");
     std::unique_ptr<dsm_server> sv(new dsm_server());
-    sv->d = nsamples; sv->device = device; sv->K = prefix_len; sv->U = prefix_len >= 0 ? (u32)prefix_len + 1 : 0;
+    sv->d = nsamples; sv->device = device; sv->K = prefix_len; sv->U = prefix_len >= 0 ? (u32)(prefix_len + 1 + unit_extra) : 0;
     sv->prm = *p;
     sv->prm.world_size = 1; sv->prm.rank = 0; sv->prm.fmin = 0; sv->prm.maxdepth = ~0u; sv->prm.prefix = "";  // as dsm_merge
     sv->sink = sink; sv->ctx = ctx;
@@ -4465,7 +4609,11 @@ int dsm_server_create(int nsamples, int device, int prefix_len, const dsm_params
     if (const char* e = getenv("DSM_TRIE_WINDOW")) { const long w = atol(e); if (w > 0) sv->WINDOW = (size_t)w; }
     for (int k = 0; k < nsamples; ++k) {
         sv->s.emplace_back(new dsm_server::Stream());
-        if (prefix_len >= 0) sv->s.back()->sp.unit_depth = sv->U;
+        if (prefix_len >= 0) {
+            dsm::StreamParser& sp = sv->s.back()->sp;
+            sp.unit_depth = sv->U; sp.chain_len = (u32)prefix_len;
+            if (prefix_len == 0) sp.last_closed.assign(1, -1);
+        }
         else if (int rc = dsm_trie_stream_begin(device, &sv->s.back()->classic)) return rc;
     }
     if (prefix_len >= 0) { dsm_server* raw = sv.get(); sv->merger = std::thread([raw] { raw->merger_main(); }); }

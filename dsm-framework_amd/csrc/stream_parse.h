@@ -26,27 +26,43 @@ struct HostTrieLevel {
     std::vector<u32> fc;
 };
 
-// A closed node of the unit depth (see StreamParser::unit_depth): what a merge that runs while the stream is still arriving needs
-// of the subtree that just ended -- its root's entry and, per deeper level, how many entries the stream held at that moment (the
-// subtree's entries of a level are the ones between the previous unit's mark and this one: levels are in path order).
-struct UnitMark {
-    u8 sym = 0;               // 0..3
-    u64 freq = 0;
-    u8 pl = 0;
-    u32 fc = 0;               // index of its first child inside level unit_depth + 1
-    std::vector<u64> upto;    // upto[k]: entries of level unit_depth + 1 + k at the close of the unit
+// Merging while receiving (dsm_server_*).  The streams of one server all start with the same enforced path of chain_len symbols
+// (metaenumerate's prefix, EnumerateQuery.cpp:240-290): every level down to chain_len holds ONE node.  The nodes of depth unit_depth
+// (> chain_len) are the UNITS: when one closes, the decoder notes how far every deeper level has grown -- the levels are in path
+// order, so the unit's subtree is the range of each level between the previous unit's mark and this one.  The nodes between the
+// path and the units ("top" nodes, depths chain_len + 1 .. unit_depth - 1) and the units close in the stream's post-order; the
+// decoder lists those closes (events) and keeps the stream's position -- the open path below the prefix and the last child closed
+// under every open node -- from which a consumer tells whether the stream can still produce a given event.
+struct UnitEvent {
+    std::vector<u8> path;     // symbols (0..3) of the node below the enforced path: 1 .. unit_depth - chain_len of them
+    u64 index = 0;            // of the node inside its level
+    std::vector<u64> upto;    // units only: upto[k] = entries of level unit_depth + 1 + k when the unit closed
 };
+// p before q in the post-order of the union trie?  (children before their parent, siblings in symbol order)
+inline bool post_before(const std::vector<u8>& p, const std::vector<u8>& q) {
+    const size_t m = p.size() < q.size() ? p.size() : q.size();
+    for (size_t i = 0; i < m; ++i)
+        if (p[i] != q[i]) return p[i] < q[i];
+    return p.size() > q.size();   // q is a proper prefix of p: the descendant comes first (equal paths: not before)
+}
 
 struct StreamParser {
-    // Merging while receiving (dsm_server_*): the streams of one server all start with the same enforced path of unit_depth - 1
-    // symbols (metaenumerate's prefix, EnumerateQuery.cpp:240-290), so every level above unit_depth holds ONE node; the nodes of
-    // depth unit_depth are the units.  0 = off.  A stream that contradicts the hint (two nodes above the unit depth) is refused.
-    u32 unit_depth = 0;
-    std::vector<u8> unit_opened;     // symbols of the units opened so far, in stream order
-    std::vector<UnitMark> unit_closed;
-    std::vector<u8> chain_sym;       // symbols of the nodes above the unit depth (depth 1 ..), as far as the stream has them
-    struct ChainEnd { u64 freq = 0; u8 pl = 0; bool closed = false; };
-    std::vector<ChainEnd> chain;     // their entries once closed (they close when the stream ends)
+    u32 unit_depth = 0;              // 0: no bookkeeping
+    u32 chain_len = 0;
+    std::vector<u8> chain_sym;       // symbols of the nodes of the enforced path (depth 1 .. chain_len), as far as the stream has them
+    std::vector<UnitEvent> events;   // closes at the depths chain_len + 1 .. unit_depth, in the order they happened
+    std::vector<u8> open_path;       // symbols of the open nodes of those depths
+    std::vector<int> last_closed;    // last_closed[k]: symbol of the last child closed under the open node of depth chain_len + k (-1: none)
+    // can the stream still produce the event with this path?  (false once it is past it; the caller adds "or the stream has ended")
+    bool may_produce(const std::vector<u8>& ev) const {
+        if (stack.size() - 1 < chain_len) return true;   // still on its way down the enforced path (or not started)
+        const size_t m = open_path.size(), n = ev.size();
+        const size_t c = m < n ? m : n;
+        for (size_t i = 0; i < c; ++i)
+            if (open_path[i] != ev[i]) return open_path[i] < ev[i];
+        if (m >= n) return true;                          // inside the event's subtree (or at the node itself, still open)
+        return (int)ev[m] > last_closed[m];               // at an ancestor: the branch towards the event is still ahead
+    }
     // Level l holds the entries [base[l], base[l] + L[l].freq.size()) of that level; earlier ones were taken by the consumer.
     std::vector<HostTrieLevel> L;
     std::vector<u64> base;
@@ -125,11 +141,14 @@ private:
                 me.freq.push_back(0); me.pl.push_back(0); me.fc.push_back(0);
                 if (count(depth + 1) > 0xFFFFFFF0ull) return fail(DSM_E_CAPACITY, "stream: level too wide");
                 if (unit_depth) {
-                    if (depth + 1 < unit_depth) {
-                        if (count(depth + 1) > 1) return fail(DSM_E_FORMAT, "stream: two nodes above the unit depth (the prefix length given to the server is too long for this stream)");
+                    if (depth + 1 <= chain_len) {
+                        if (count(depth + 1) > 1) return fail(DSM_E_FORMAT, "stream: two nodes on the enforced path (the prefix length given to the server is too long for this stream)");
                         chain_sym.push_back((u8)k);
-                    } else if (depth + 1 == unit_depth) {
-                        unit_opened.push_back((u8)k);
+                        if (depth + 1 == chain_len) last_closed.assign(1, -1);
+                    } else if (depth + 1 <= unit_depth) {
+                        open_path.push_back((u8)k);
+                        last_closed.resize(open_path.size() + 1);
+                        last_closed[open_path.size()] = -1;
                     }
                 }
                 stack.push_back(count(depth + 1) - 1);
@@ -156,14 +175,15 @@ private:
                 me.freq[mi] = f;
                 me.pl[mi] |= (u8)(code << 4);
                 mf = f > mf ? f : mf;
-                if (unit_depth && depth == unit_depth) {
-                    UnitMark um;
-                    um.sym = unit_opened.back(); um.freq = f; um.pl = me.pl[mi]; um.fc = me.fc[mi];
-                    for (size_t l = depth + 1; l < L.size(); ++l) um.upto.push_back(count(l));
-                    unit_closed.push_back(std::move(um));
-                } else if (unit_depth && depth < unit_depth) {
-                    if (chain.size() < depth) chain.resize(depth);
-                    chain[depth - 1].freq = f; chain[depth - 1].pl = me.pl[mi]; chain[depth - 1].closed = true;
+                if (unit_depth && depth > chain_len && depth <= unit_depth) {
+                    UnitEvent ev;
+                    ev.path = open_path;
+                    ev.index = stack.back();
+                    if (depth == unit_depth)
+                        for (size_t l = depth + 1; l < L.size(); ++l) ev.upto.push_back(count(l));
+                    events.push_back(std::move(ev));
+                    last_closed[open_path.size() - 1] = (int)open_path.back();
+                    open_path.pop_back();
                 }
                 stack.pop_back();
             }

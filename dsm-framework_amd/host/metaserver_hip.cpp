@@ -4,9 +4,10 @@
 // they arrive (dsm_server_feed: the reference's token rules and R checksums; what is decoded moves to the card in windows, so the
 // host never holds a stream).  With --prefix-len K (the length of the prefix this server's clients enforce: one server per prefix,
 // wrapper-SLURM/example-server.sh:27-41) the streams are merged WHILE they arrive, as the reference's traverse() does
-// (metaserver.cpp:682-739): the subtree of every node of depth K + 1 is merged on the GPU and printed as soon as every connection
-// is past it, and leaves the card.  Without the option the merge starts when the last stream has ended.
-//   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] [--prefix-len K] < names.txt
+// (metaserver.cpp:682-739): the subtree of every node of depth K + 1 + X (--unit-extra X, default 1: up to 16 subtrees) is merged on
+// the GPU and printed as soon as every connection is past it, and leaves the card.  Without --prefix-len the merge starts when the
+// last stream has ended.
+//   metaserver_hip -E emax [-e emin] [-P pmin] [--pmax N] [-p port] [-m mindepth] [-v] [--device D] [--prefix-len K [--unit-extra X]] < names.txt
 #include <getopt.h>
 #include <netinet/in.h>
 #include <sys/socket.h>
@@ -37,13 +38,14 @@ int main(int argc, char** argv) {
     if (argc <= 1) { std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1; }
     dsm_params p;
     dsm_params_default(&p);
-    int port = 54666, device = 0, prefix_len = -1;  // metaserver.cpp:515
+    int port = 54666, device = 0, prefix_len = -1, unit_extra = 1;  // metaserver.cpp:515
     bool verbose = false;
     static option long_options[] = {{"pmin", required_argument, 0, 'P'},     {"pmax", required_argument, 0, 258},
                                     {"port", required_argument, 0, 'p'},     {"mindepth", required_argument, 0, 'm'},
                                     {"emin", required_argument, 0, 'e'},     {"emax", required_argument, 0, 'E'},
                                     {"verbose", no_argument, 0, 'v'},        {"debug", no_argument, 0, 256},
                                     {"device", required_argument, 0, 257},   {"prefix-len", required_argument, 0, 259},
+                                    {"unit-extra", required_argument, 0, 260},
                                     {0, 0, 0, 0}};
     int c, oi = 0;
     while ((c = getopt_long(argc, argv, "P:p:m:e:E:F:T:vA", long_options, &oi)) != -1) {
@@ -58,6 +60,7 @@ int main(int argc, char** argv) {
             case 256: case 'F': case 'T': case 'A': break;  // progress options of the reference: accepted, no effect
             case 257: device = atoi(optarg); break;
             case 259: prefix_len = atoi(optarg); if (prefix_len < 0 || prefix_len > 32) { std::cerr << argv[0] << ": argument of --prefix-len must be 0..32" << std::endl; return 1; } break;
+            case 260: unit_extra = atoi(optarg); if (unit_extra < 0 || unit_extra > 4) { std::cerr << argv[0] << ": argument of --unit-extra must be 0..4" << std::endl; return 1; } break;
             default: std::cerr << "usage: " << argv[0] << " [options] < names.txt" << std::endl; return 1;
         }
     }
@@ -90,7 +93,7 @@ int main(int argc, char** argv) {
     std::vector<bool> seen(d, false);
     std::vector<std::thread> readers;
     dsm_server* srv = nullptr;
-    if (dsm_server_create((int)d, device, prefix_len, &p, print_batch, nullptr, &srv)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+    if (dsm_server_create((int)d, device, prefix_len, unit_extra, &p, print_batch, nullptr, &srv)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
     std::string perr;
     std::mutex err_mu;
     size_t pending = d;

@@ -134,7 +134,7 @@ def lib():
         L.dsm_trie_nodes.restype = C.c_uint64
         L.dsm_trie_nodes.argtypes = [C.c_void_p]
         L.dsm_merge.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(Stats)]
-        L.dsm_server_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dsm_server_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params), TUPLE_SINK, C.c_void_p, C.POINTER(C.c_void_p)]
         L.dsm_server_feed.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
         L.dsm_server_end.argtypes = [C.c_void_p, C.c_int]
         L.dsm_server_finish.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -575,19 +575,19 @@ def merge(tries, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0,
 
 class Server:
     """One metaserver (dsm_server_*): the streams of `nsamples` connections, merged while they arrive when prefix_len (the length of
-    the prefix the clients enforce) is given -- the subtree of every node of depth prefix_len + 1 is merged and delivered as soon
-    as all connections are past it -- or kept and merged by finish() (prefix_len=None).  feed(sample, bytes) takes the bytes of
+    the prefix the clients enforce) is given -- the subtree of every node of depth prefix_len + 1 + unit_extra is merged and delivered
+    as soon as all connections are past it -- or kept and merged by finish() (prefix_len=None).  feed(sample, bytes) takes the bytes of
     a connection after its handshake; tuples arrive in the reference's order."""
 
-    def __init__(self, nsamples, prefix_len=None, device=0, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0, text=True,
-                 on_batch=None):
+    def __init__(self, nsamples, prefix_len=None, unit_extra=0, device=0, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0,
+                 text=True, on_batch=None):
         self._keep = []
         p = _make_params(0, MAXDEPTH_NONE, pmin, pmax, mindepth, emin, emax, 1, 0, None, None, arena_bytes, 0, None, self._keep)
         self.out, self._err = [], []
         self._cb = _tuple_sink(self.out, text, on_batch, self._err)
         self.h = C.c_void_p()
-        _check(lib().dsm_server_create(int(nsamples), device, -1 if prefix_len is None else int(prefix_len), C.byref(p), self._cb, None,
-                                       C.byref(self.h)))
+        _check(lib().dsm_server_create(int(nsamples), device, -1 if prefix_len is None else int(prefix_len), int(unit_extra), C.byref(p),
+                                       self._cb, None, C.byref(self.h)))
 
     def feed(self, sample, data):
         _check_sink(lib().dsm_server_feed(self.h, int(sample), data, len(data)), self._err)

@@ -260,16 +260,17 @@ int dsm_merge(dsm_trie* const* tries, int n, const dsm_params* p, dsm_tuple_sink
 /* One metaserver: nsamples connections whose streams are merged WHILE they arrive (metaserver.cpp:682-739: the reference reads its
  * sockets token by token inside traverse(), holds no stream and prints a node as soon as every client has closed it).  Every client
  * of a server enforces the same prefix (metaenumerate.cpp:268-309, EnumerateQuery.cpp:240-290); prefix_len is its length (the server
- * wrapper knows it: one server per prefix, wrapper-SLURM/example-server.sh:27-41).  The subtree of a node of depth prefix_len + 1 is
- * merged and its tuples delivered as soon as every connection has closed it, gone past it or ended -- while the later subtrees are
- * still being received -- and leaves the device; the nodes of the prefix itself, which close last, follow at the end: the sink sees
- * the tuples in the reference's order, the card holds the subtrees in flight instead of nsamples complete streams.  A stream that is
- * not a single path above that depth is refused (DSM_E_FORMAT).  prefix_len < 0: the streams are kept and merged by dsm_server_finish
+ * wrapper knows it: one server per prefix, wrapper-SLURM/example-server.sh:27-41).  The subtree of a node of depth prefix_len + 1 +
+ * unit_extra (unit_extra = 0..4: 4, 16, .. 1024 units at most) is merged and its tuples delivered as soon as every connection has
+ * closed it, gone past it or ended -- while the later subtrees are still being received -- and leaves the device; a node between the
+ * prefix and the units is delivered when its last child has been; the nodes of the prefix itself, which close last, follow at the end:
+ * the sink sees the tuples in the reference's order, the card holds the subtrees in flight instead of nsamples complete streams.  A
+ * stream that is not a single path down to depth prefix_len is refused (DSM_E_FORMAT).  prefix_len < 0: the streams are kept and merged by dsm_server_finish
  * (dsm_trie_stream_* + dsm_merge).  _feed / _end: one thread per sample (the connection's reader), any number of samples side by
  * side; the sink is called from a thread of the library.  sample = the id the reference gives the connection (position of its name
  * in the server's list).  _finish: after every connection has ended; waits for what is left and returns the totals. */
 typedef struct dsm_server dsm_server;
-int dsm_server_create(int nsamples, int device, int prefix_len, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_server** out);
+int dsm_server_create(int nsamples, int device, int prefix_len, int unit_extra, const dsm_params* p, dsm_tuple_sink sink, void* ctx, dsm_server** out);
 int dsm_server_feed(dsm_server* s, int sample, const uint8_t* bytes, size_t n);
 int dsm_server_end(dsm_server* s, int sample);
 int dsm_server_finish(dsm_server* s, dsm_stats* stats);

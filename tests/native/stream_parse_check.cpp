@@ -34,7 +34,11 @@ int main(int argc, char** argv) {
         // the incremental decoder fed `piece` bytes at a time, with a consumer that takes every final entry away after each piece
         // (the way dsm_trie_stream moves them to the card): the collected levels must equal the one-shot parse
         dsm::StreamParser sp;
-        if (argc > 3) sp.unit_depth = (dsm::u32)atol(argv[3]);
+        if (argc > 3) {  // unit depth [prefix length, default unit depth - 1]
+            sp.unit_depth = (dsm::u32)atol(argv[3]);
+            sp.chain_len = argc > 4 ? (dsm::u32)atol(argv[4]) : sp.unit_depth - 1;
+            if (sp.chain_len == 0) sp.last_closed.assign(1, -1);
+        }
         auto take = [&]() {
             if (L.size() < sp.L.size()) L.resize(sp.L.size());
             for (size_t l = 0; l < sp.L.size(); ++l) {
@@ -58,14 +62,20 @@ int main(int argc, char** argv) {
             for (auto c : sp.chain_sym) g_units += "ACGT"[c];
             g_units += " units=";
             std::vector<dsm::u64> from;
-            for (size_t q = 0; q < sp.unit_closed.size(); ++q) {
-                const dsm::UnitMark& um = sp.unit_closed[q];
-                if (from.size() < um.upto.size()) from.resize(um.upto.size(), 0);
+            bool first = true;
+            for (const dsm::UnitEvent& ev : sp.events) {
+                std::string path;
+                for (auto c : ev.path) path += "ACGT"[c];
                 dsm::u64 sz = 1;
-                for (size_t k = 0; k < um.upto.size(); ++k) { sz += um.upto[k] - from[k]; from[k] = um.upto[k]; }
-                g_units += (q ? "," : "") + std::string(1, "ACGT"[um.sym]) + ":" + std::to_string(sz) + ":" + std::to_string(um.freq);
+                if (ev.path.size() == sp.unit_depth - sp.chain_len) {  // a unit: nodes of its subtree from the marks
+                    if (from.size() < ev.upto.size()) from.resize(ev.upto.size(), 0);
+                    for (size_t k = 0; k < ev.upto.size(); ++k) { sz += ev.upto[k] - from[k]; from[k] = ev.upto[k]; }
+                } else {
+                    sz = 0;                                            // a node between the path and the units
+                }
+                g_units += (first ? "" : ",") + path + ":" + std::to_string(sz) + ":" + std::to_string(L[sp.chain_len + ev.path.size()].freq[ev.index]);
+                first = false;
             }
-            if (sp.unit_closed.size() != sp.unit_opened.size()) g_units += " OPEN";
         }
     }
     if (rc) { printf("error: %s\n", g_err.c_str()); return 1; }

@@ -139,23 +139,25 @@ def test_server_merges_subtrees_while_the_streams_arrive(golden, pydsm_mod):
     names = m["names"]
     for p in ["A", "C", "G", "T", "AC", "GT", "TTG"]:
         bodies = [_body(golden.stream("toy3", n, p)) for n in names]
-        for cfg, args in m["server_cfgs"].items():
+        for ci, (cfg, args) in enumerate(m["server_cfgs"].items()):
             if p == "TTG" and cfg != "default":
                 continue
-            srv = pydsm_mod.Server(len(names), prefix_len=len(p), **server_args_to_kw(args))
-            _feed_round_robin(srv, bodies, [4096, 1000, 77])
-            got, st = srv.finish()
-            units, peak = srv.units()
-            srv.close()
-            assert got == golden.server_out("toy3", cfg, p), (cfg, p)
-            assert st.tuples == got.count(b"\n")
-            assert 1 <= units <= 4 and peak > 0
+            # units one, two or three levels below the prefix (4, 16, 64 subtrees at most; the nodes between are printed between them)
+            for extra in ((0, 1, 2) if cfg == "default" else ((ci + len(p)) % 3,)):
+                srv = pydsm_mod.Server(len(names), prefix_len=len(p), unit_extra=extra, **server_args_to_kw(args))
+                _feed_round_robin(srv, bodies, [4096, 1000, 77])
+                got, st = srv.finish()
+                units, peak = srv.units()
+                srv.close()
+                assert got == golden.server_out("toy3", cfg, p), (cfg, p, extra)
+                assert st.tuples == got.count(b"\n")
+                assert 1 <= units <= 4 ** (extra + 1) and peak > 0
     want = golden.server_out("toy3", "default", "A")
     os.environ["DSM_TRIE_WINDOW"] = "64"   # windows of the levels go to the card (and leave it with a unit) all the time
     try:
         bodies = [_body(golden.stream("toy3", n, "A")) for n in names]
         # one connection far ahead of the others, one far behind: a unit waits for the slowest stream
-        srv = pydsm_mod.Server(len(names), prefix_len=1, emax=2.0)
+        srv = pydsm_mod.Server(len(names), prefix_len=1, unit_extra=1, emax=2.0)
         srv.feed(0, bodies[0]); srv.end(0)
         for o in range(0, len(bodies[1]), 513):
             srv.feed(1, bodies[1][o:o + 513])
@@ -164,11 +166,11 @@ def test_server_merges_subtrees_while_the_streams_arrive(golden, pydsm_mod):
             srv.feed(2, bodies[2][o:o + 9999])
         srv.end(2)
         got, _ = srv.finish()
-        assert srv.units()[0] == 4
+        assert srv.units()[0] == 16
         srv.close()
         assert got == want
         # the connections' reader threads side by side (what metaserver_hip does)
-        srv = pydsm_mod.Server(len(names), prefix_len=1, emax=2.0)
+        srv = pydsm_mod.Server(len(names), prefix_len=1, unit_extra=2, emax=2.0)
         def reader(i):
             b = bodies[i]
             for o in range(0, len(b), 1777 + 100 * i):
@@ -185,7 +187,7 @@ def test_server_merges_subtrees_while_the_streams_arrive(golden, pydsm_mod):
     # a hint shorter than the prefix: one unit (the whole subtree), same output; no hint: merged by finish()
     bodies = [_body(golden.stream("toy3", n, "AC")) for n in names]
     for plen in (1, 0, None):
-        srv = pydsm_mod.Server(len(names), prefix_len=plen, emax=2.0)
+        srv = pydsm_mod.Server(len(names), prefix_len=plen, unit_extra=1, emax=2.0)
         _feed_round_robin(srv, bodies, [30000])
         got, _ = srv.finish()
         srv.close()
@@ -201,7 +203,7 @@ def test_server_merges_subtrees_while_the_streams_arrive(golden, pydsm_mod):
     t1 = pydsm_mod.Trie(golden.stream("toy3", names[1], "AC"))   # only the subtree AC of A
     empty = pydsm_mod.Trie(b"Stoy-9.")
     want2, _ = pydsm_mod.merge([t0, empty, t1], pmin=1, emax=0.0)
-    srv = pydsm_mod.Server(3, prefix_len=1, pmin=1, emax=0.0)
+    srv = pydsm_mod.Server(3, prefix_len=1, unit_extra=1, pmin=1, emax=0.0)
     _feed_round_robin(srv, [_body(golden.stream("toy3", names[0], "A")), b"", _body(golden.stream("toy3", names[1], "AC"))], [5000])
     got2, _ = srv.finish()
     srv.close()

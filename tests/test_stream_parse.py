@@ -110,33 +110,39 @@ def _tokens(body):
 
 
 def test_unit_marks_of_the_decoder(golden, exe, tmp_path):
-    """dsm_server's unit of merging-while-receiving: when a node one level below the enforced prefix closes, the decoder notes how far
-    every deeper level has grown; the subtree sizes that follow from the marks equal an independent count over the token stream."""
+    """dsm_server's units of merging-while-receiving: when a node `extra` + 1 levels below the enforced prefix closes, the decoder notes
+    how far every deeper level has grown; the subtree sizes that follow from the marks, the closes of the nodes between the prefix and
+    the units and their order equal an independent reading of the token stream."""
     names = golden.manifest["sets"]["toy3"]["names"]
     for name, prefix in ((names[0], "A"), (names[1], "GT"), (names[2], "TTG")):
         body = _body(golden.stream("toy3", name, prefix))
-        U = len(prefix) + 1
-        want, cur, size = [], None, 0
-        for kind, val, depth in _tokens(body):
-            if kind == "open":
-                if depth == U:
-                    cur, size = val, 0
-                if depth >= U:
-                    size += 1
-            elif depth == U:
-                want.append("%s:%d:%d" % (cur, size, val))
-        for piece in (1, 24, 1000, 1 << 20):
-            rc, out, err = _run_units(exe, tmp_path, body, piece, U)
-            assert rc == 0, (out, err)
-            fields = dict(kv.split("=") for kv in out.split()[1:])
-            assert fields["chain"] == prefix and fields["units"] == ",".join(want), (name, prefix, piece)
-        # a hint that is too long for the stream is refused
-        rc, out, _ = _run_units(exe, tmp_path, body, 4096, U + 1)
-        assert rc == 1 and "unit depth" in out
+        K = len(prefix)
+        for extra in (0, 1, 2):
+            U = K + 1 + extra
+            want, path, sizes = [], [], {}
+            for kind, val, depth in _tokens(body):
+                if kind == "open":
+                    if depth > K:
+                        path = path[:depth - K - 1] + [val]
+                    if depth == U:
+                        sizes["".join(path[:U - K])] = 0
+                    if depth >= U:
+                        sizes["".join(path[:U - K])] += 1
+                elif K < depth <= U:
+                    key = "".join(path[:depth - K])
+                    want.append("%s:%d:%d" % (key, sizes[key] if depth == U else 0, val))
+            for piece in (1, 24, 1000, 1 << 20):
+                rc, out, err = _run_units(exe, tmp_path, body, piece, U, K)
+                assert rc == 0, (out, err)
+                fields = dict(kv.split("=") for kv in out.split()[1:])
+                assert fields["chain"] == prefix and fields["units"] == ",".join(want), (name, prefix, extra, piece)
+        # a prefix length that is too long for the stream is refused
+        rc, out, _ = _run_units(exe, tmp_path, body, 4096, K + 2, K + 1)
+        assert rc == 1 and "enforced path" in out
 
 
-def _run_units(exe, tmp_path, body, piece, unit_depth):
+def _run_units(exe, tmp_path, body, piece, unit_depth, chain_len):
     p = tmp_path / "s.bin"
     p.write_bytes(body)
-    r = subprocess.run([exe, str(p), str(piece), str(unit_depth)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([exe, str(p), str(piece), str(unit_depth), str(chain_len)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return r.returncode, r.stdout.decode().strip(), r.stderr.decode()
