@@ -588,6 +588,9 @@ def main():
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),                     # HIP events, this run
                          "rocprof_avg_launch_ms": tinfo.get("rocprof_avg_launch_ms") if traffic else None,  # kernel trace of the profiled run
                          "rocprof_expand_ms_per_step": tinfo.get("rocprof_expand_ms_per_step") if traffic else None,
+                         # what the kernel is bound by: vector-instruction issue -- SQ counters of the same offline passes
+                         "valu_busy_of_resident_wave_time": (tinfo.get("valu") or {}).get("busy_of_resident_wave_time") if traffic else None,
+                         "valu_insts_per_node": (tinfo.get("valu") or {}).get("insts_per_node") if traffic else None,
                          "bytes_per_launch": kernel_bytes / max(1, tot["launches"]),
                          "bytes_per_node": kernel_bytes / max(1, tot["reported"]),
                          "index_lines_per_node": tot["index_lines"] / max(1, tot["reported"]),

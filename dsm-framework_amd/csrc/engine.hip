@@ -1703,7 +1703,7 @@ __global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ pat
 // words of the node and of its ancestors at the chunk boundaries (levels 16, 32, ...): 16 symbols per dependent load.
 __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const LevelDev* __restrict__ lv, const u32* __restrict__ path_off,
                                                          const u32* __restrict__ pair_off, char* __restrict__ paths, u32* __restrict__ ids,
-                                                         u64* __restrict__ freqs) {
+                                                         u64* __restrict__ freqs, u32 rank_lo, u32 rank_hi) {
     // the per-level arrays and candidate bases are read by every walk: kept in LDS, with the text of every byte of four symbols
     constexpr u32 LDS_LEVELS = 1024;
     __shared__ const uint2* s_pw[LDS_LEVELS];
@@ -1728,6 +1728,7 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
     const LevelDev L = lv[lvl];
     const u32 k = f - L.cbase;
     const u32 r = L.crank[k];
+    if (r < rank_lo || r >= rank_hi) return;  // (a launch fills one chunk of consecutive output ranks)
     const u32 b = L.cand_poff[k];
     const u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
     u32 o = pair_off[r];
@@ -3608,15 +3609,17 @@ class Engine {
         if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
         if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
         E.nchunk = cbs.n;
-        // one fill for the whole prefix (its threads follow the levels, not the output order); the copies and the host's work
-        // stay chunked by output rank
-        hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs);
-        DSM_HIP(hipGetLastError());
-        if (!chunk_filled[0]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[0], hipEventDisableTiming));
-        DSM_HIP(hipEventRecord(chunk_filled[0], st));
-        DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[0], 0));
-        for (int c = 0; c < cbs.n; ++c) {  // copy and signal chunk by chunk
+        // One fill per chunk of output ranks (its threads follow the levels, not the output order: every launch looks at all candidates and
+        // keeps the ones of its chunk), so that a chunk is on its way to the host while the next one is being filled -- what shows at
+        // the end of a pass, where nothing else hides the last prefix's copy (1 GB, 20 ms, behind a 14 ms fill).
+        if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (int c = 0; c < cbs.n; ++c) {  // fill, copy and signal chunk by chunk
             const u32 t0 = cbs.tb[c], t1 = cbs.tb[c + 1];
+            hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs, t0, t1);
+            DSM_HIP(hipGetLastError());
+            if (!chunk_filled[c]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[c], hipEventDisableTiming));
+            DSM_HIP(hipEventRecord(chunk_filled[c], st));
+            DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
             E.cb[c] = t0; E.cb[c + 1] = t1;
             if (!E.cready[c]) DSM_HIP(hipEventCreateWithFlags(&E.cready[c], hipEventDisableTiming));
             const u64 pb0 = h_totals[16 + 2 * c], qb0 = h_totals[17 + 2 * c], pb1 = h_totals[16 + 2 * (c + 1)], qb1 = h_totals[17 + 2 * (c + 1)];

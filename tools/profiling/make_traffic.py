@@ -66,6 +66,15 @@ def traffic(pmc_path, bench_path, trace_path):
            "sq": {k: v[0] for k, v in agg.items() if k.startswith("SQ_")},
            "source": "tools/profiling/r03_final.sh on one box: bench.py --steps 3 --warmup 1 (JSON line and kernel trace), then one "
                      "rocprofv3 --pmc pass per counter group of bench.py --steps 1 --warmup 0 --no-cpu --no-extras"}
+    sq = out["sq"]
+    if "SQ_INSTS_VALU" in sq and "SQ_WAVE_CYCLES" in sq and sq["SQ_WAVE_CYCLES"]:
+        clock_hz = 2.34e9   # measured inside the kernel (s_memtime against s_memrealtime, tools/profiling/clock_probe.sh)
+        kernel_s = bench["detail"]["expand_ms_per_step"] * 1e-3
+        out["valu"] = {"insts_per_pass": sq["SQ_INSTS_VALU"] / passes, "insts_per_node": sq["SQ_INSTS_VALU"] / passes / nodes,
+                       # SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count quad-cycles per wave; four waves share a SIMD
+                       "busy_of_resident_wave_time": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
+                       "busy_of_kernel_time": sq["SQ_INSTS_VALU"] / passes * 4.0 / (1024 * kernel_s * clock_hz),
+                       "resident_waves_avg": sq["SQ_WAVE_CYCLES"] / passes * 4.0 / (kernel_s * clock_hz), "clock_hz": clock_hz}
     print(json.dumps(out, indent=1))
 
 
