@@ -4195,15 +4195,49 @@ struct ServerOrder {  // Engine<P>::NodeOrder without the position type
 };
 // one engine run over the given tries (sample id = position): capture (shallow pass, nothing emitted), a unit (run_auto: a unit that
 // does not fit the buffers splits like any prefix) or the closing pass over the depths lo..hi
+// An engine a server keeps: created for tries of up to `cap` nodes each (place holders size its buffers) and pointed at the tries of
+// every run that fits; a run that does not fit gets a new, larger one.  (Creating an engine costs ~50 ms of allocations; a server
+// runs dozens of small passes over the tops of its streams and one pass per unit.)
+template <typename P>
+struct KeptEngine {
+    std::unique_ptr<MinerT<P>> m;
+    u64 cap = 0;
+};
 template <typename P>
 static int server_run_t(dsm_trie* const* tr, int n, const dsm_params& q, const std::string& prefix, dsm_tuple_sink sink, void* ctx, bool emit,
-                        u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out) {
-    std::unique_ptr<MinerT<P>> m(new MinerT<P>());
-    int rc = m->e.init_tries(tr, n, q);
-    if (rc) return rc;
+                        u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out, KeptEngine<P>* keep, u64 min_cap) {
+    std::unique_ptr<MinerT<P>> own;
+    MinerT<P>* m = nullptr;
+    u64 need = 0;
+    for (int k = 0; k < n; ++k) need = tr[k]->nodes > need ? tr[k]->nodes : need;
+    if (keep && keep->m && need <= keep->cap) {
+        m = keep->m.get();
+        memset(&m->e.stats, 0, sizeof m->e.stats);
+    } else {
+        own.reset(new MinerT<P>());
+        m = own.get();
+        int rc;
+        if (keep) {
+            const u64 cap = need * 2 > min_cap ? need * 2 : min_cap;
+            std::vector<dsm_trie> ph(n);
+            std::vector<dsm_trie*> pp(n);
+            for (int k = 0; k < n; ++k) { ph[k].device = tr[k]->device; ph[k].nodes = cap; pp[k] = &ph[k]; }
+            keep->m.reset();  // (the old one's buffers go first)
+            rc = m->e.init_tries(pp.data(), n, q);
+            if (rc) return rc;
+            keep->m = std::move(own);
+            keep->cap = cap;
+        } else {
+            rc = m->e.init_tries(tr, n, q);
+            if (rc) return rc;
+        }
+    }
+    if (keep)
+        for (int k = 0; k < n; ++k) m->e.tries[k] = tr[k];
     typename Engine<P>::NodeOrder sd, cp;
     if (seed) { sd.depth = seed->depth; sd.sym = seed->sym; sd.ord = seed->ord; }
     if (capture) cp.depth = capture->depth;
+    int rc;
     if (capture || hi != ~0u) rc = m->e.run(prefix.c_str(), sink, nullptr, ctx, emit, lo, hi, expand_cap, seed ? &sd : nullptr, capture ? &cp : nullptr, capture == nullptr);
     else rc = m->run_auto(prefix, sink, ctx, emit, lo, seed ? &sd : nullptr);
     const int rc2 = m->e.finish_emits();
@@ -4211,10 +4245,17 @@ static int server_run_t(dsm_trie* const* tr, int n, const dsm_params& q, const s
     if (out) *out = m->e.stats;
     return rc ? rc : rc2;
 }
+struct ServerEngines {  // for the passes over the tops of the streams (top) and for the units (unit)
+    KeptEngine<u32> top32, unit32;
+    KeptEngine<u64> top64, unit64;
+};
+// which: 0 = an engine for this run only, 1 = the kept engine for tops, 2 = the kept engine for units
 static int server_run(bool wide, dsm_trie* const* tr, int n, const dsm_params& q, const std::string& prefix, dsm_tuple_sink sink, void* ctx,
-                      bool emit, u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out) {
-    return wide ? server_run_t<u64>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out)
-                : server_run_t<u32>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out);
+                      bool emit, u32 lo, u32 hi, u32 expand_cap, const ServerOrder* seed, ServerOrder* capture, dsm_stats* out, ServerEngines* keep = nullptr,
+                      int which = 0) {
+    const u64 min_cap = which == 1 ? 65536 : (1u << 20);
+    if (wide) return server_run_t<u64>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out, !keep || !which ? nullptr : (which == 1 ? &keep->top64 : &keep->unit64), min_cap);
+    return server_run_t<u32>(tr, n, q, prefix, sink, ctx, emit, lo, hi, expand_cap, seed, capture, out, !keep || !which ? nullptr : (which == 1 ? &keep->top32 : &keep->unit32), min_cap);
 }
 }  // namespace dsm
 
@@ -4225,12 +4266,13 @@ struct dsm_server {
         dsm::u8* pl = nullptr;
         dsm::u32* fc = nullptr;
         size_t n = 0, cap = 0;
-        dsm::u64 abs0 = 0;  // index, inside its level of the stream, of the first entry held
+        size_t head = 0;    // entries at the front that left with a unit (their room is reclaimed when the window is next copied)
+        dsm::u64 abs0 = 0;  // index, inside its level of the stream, of the first entry still held (= entry `head` of the arrays)
         void release() {
             if (freq) (void)hipFree(freq);
             if (pl) (void)hipFree(pl);
             if (fc) (void)hipFree(fc);
-            freq = nullptr; pl = nullptr; fc = nullptr; n = cap = 0;
+            freq = nullptr; pl = nullptr; fc = nullptr; n = cap = 0; head = 0;
         }
     };
     struct Stream {
@@ -4271,22 +4313,24 @@ struct dsm_server {
             if (st->whole) dsm_trie_free(st->whole);
         }
     }
+    // room for `need` live entries (v.n of them are held, behind v.head dead ones): a new allocation takes the live ones only
     int grow(DevLevel& v, size_t need) {
         using namespace dsm;
-        if (need <= v.cap) return 0;
+        if (v.head + need <= v.cap) return 0;
         size_t cap = v.cap ? v.cap * 2 : WINDOW;
+        if (need <= v.cap / 2) cap = v.cap;  // (mostly dead entries: the same size will do)
         if (cap < need) cap = need;
         DevLevel w;
         hipError_t e = hipMalloc((void**)&w.freq, cap * sizeof(u64));
         if (e == hipSuccess) e = hipMalloc((void**)&w.pl, cap);
         if (e == hipSuccess) e = hipMalloc((void**)&w.fc, cap * sizeof(u32));
         if (e == hipSuccess && v.n) {
-            e = hipMemcpy(w.freq, v.freq, v.n * sizeof(u64), hipMemcpyDeviceToDevice);
-            if (e == hipSuccess) e = hipMemcpy(w.pl, v.pl, v.n, hipMemcpyDeviceToDevice);
-            if (e == hipSuccess) e = hipMemcpy(w.fc, v.fc, v.n * sizeof(u32), hipMemcpyDeviceToDevice);
+            e = hipMemcpy(w.freq, v.freq + v.head, v.n * sizeof(u64), hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(w.pl, v.pl + v.head, v.n, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(w.fc, v.fc + v.head, v.n * sizeof(u32), hipMemcpyDeviceToDevice);
         }
         if (e != hipSuccess) { w.release(); return fail(DSM_E_NOMEM, std::string("dsm_server: ") + hipGetErrorString(e)); }
-        w.n = v.n; w.cap = cap; w.abs0 = v.abs0;
+        w.n = v.n; w.cap = cap; w.abs0 = v.abs0; w.head = 0;
         v.release();
         v = w;
         return 0;
@@ -4301,9 +4345,9 @@ struct dsm_server {
             DevLevel& v = st.dl[l];
             if (int r = grow(v, v.n + k)) return r;
             const HostTrieLevel& h = st.sp.L[l];
-            DSM_HIP(hipMemcpy(v.freq + v.n, h.freq.data(), k * sizeof(u64), hipMemcpyHostToDevice));
-            DSM_HIP(hipMemcpy(v.pl + v.n, h.pl.data(), k, hipMemcpyHostToDevice));
-            DSM_HIP(hipMemcpy(v.fc + v.n, h.fc.data(), k * sizeof(u32), hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.freq + v.head + v.n, h.freq.data(), k * sizeof(u64), hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.pl + v.head + v.n, h.pl.data(), k, hipMemcpyHostToDevice));
+            DSM_HIP(hipMemcpy(v.fc + v.head + v.n, h.fc.data(), k * sizeof(u32), hipMemcpyHostToDevice));
             v.n += k;
             st.sp.drop_front(l, k);
         }
@@ -4401,6 +4445,7 @@ struct dsm_server {
         DSM_HIP(hipMemcpy(t->d_pl, pl.data(), f.size(), hipMemcpyHostToDevice));
         DSM_HIP(hipMemcpy(t->d_fc, fc.data(), f.size() * sizeof(u32), hipMemcpyHostToDevice));
         u64 o = (u64)U + 1;
+        std::vector<size_t> reclaim;
         for (size_t k = 0; k < nl; ++k) {
             const size_t l = (size_t)U + 1 + k;
             const u64 a = st.from[k], b = ev.upto[k], cnt = b - a;
@@ -4408,28 +4453,33 @@ struct dsm_server {
             t->level_off.push_back(o);
             DevLevel& v = st.dl[l];
             if (v.abs0 != a || v.abs0 + v.n < b) return fail(DSM_E_HIP, "dsm_server: a unit's entries are not in the device window");
-            DSM_HIP(hipMemcpy(t->d_freq + o, v.freq, cnt * sizeof(u64), hipMemcpyDeviceToDevice));
-            DSM_HIP(hipMemcpy(t->d_pl + o, v.pl, cnt, hipMemcpyDeviceToDevice));
-            DSM_HIP(hipMemcpy(t->d_fc + o, v.fc, cnt * sizeof(u32), hipMemcpyDeviceToDevice));
+            DSM_HIP(hipMemcpyAsync(t->d_freq + o, v.freq + v.head, cnt * sizeof(u64), hipMemcpyDeviceToDevice, 0));
+            DSM_HIP(hipMemcpyAsync(t->d_pl + o, v.pl + v.head, cnt, hipMemcpyDeviceToDevice, 0));
+            DSM_HIP(hipMemcpyAsync(t->d_fc + o, v.fc + v.head, cnt * sizeof(u32), hipMemcpyDeviceToDevice, 0));
             const u64 child_from = k + 1 < nl ? st.from[k + 1] : 0;  // entries of the next level count from the unit's first one
             if (child_from) hipLaunchKernelGGL(fc_rebase_kernel, grid_for(cnt), dim3(256), 0, 0, t->d_fc + o, (size_t)cnt, (u32)child_from);
-            // what is left of the level (entries of later units) moves to a window of its own
-            const size_t rest = v.n - (size_t)cnt;
-            DevLevel w;
-            if (rest) {
-                if (int r = grow(w, rest)) return r;
-                DSM_HIP(hipMemcpy(w.freq, v.freq + cnt, rest * sizeof(u64), hipMemcpyDeviceToDevice));
-                DSM_HIP(hipMemcpy(w.pl, v.pl + cnt, rest, hipMemcpyDeviceToDevice));
-                DSM_HIP(hipMemcpy(w.fc, v.fc + cnt, rest * sizeof(u32), hipMemcpyDeviceToDevice));
-                w.n = rest;
-            }
-            w.abs0 = b;
-            DSM_HIP(hipDeviceSynchronize());
-            v.release();
-            v = w;
+            // the unit's entries stay where they are, dead: the window gives their room back when it is next copied (grow)
+            v.head += (size_t)cnt;
+            v.n -= (size_t)cnt;
+            v.abs0 = b;
             o += cnt;
+            if (v.n == 0 || v.head > 2 * v.n) reclaim.push_back(l);
         }
         DSM_HIP(hipDeviceSynchronize());
+        for (size_t l : reclaim) {  // windows that are mostly dead now give the room back (one wait for all of them, above)
+            DevLevel& v = st.dl[l];
+            if (v.n == 0) { if (v.cap > 4 * WINDOW) v.release(); else v.head = 0; }
+            else {
+                DevLevel w;
+                if (int r = grow(w, v.n > WINDOW ? v.n : WINDOW)) return r;
+                DSM_HIP(hipMemcpy(w.freq, v.freq + v.head, v.n * sizeof(u64), hipMemcpyDeviceToDevice));
+                DSM_HIP(hipMemcpy(w.pl, v.pl + v.head, v.n, hipMemcpyDeviceToDevice));
+                DSM_HIP(hipMemcpy(w.fc, v.fc + v.head, v.n * sizeof(u32), hipMemcpyDeviceToDevice));
+                w.n = v.n; w.abs0 = v.abs0;
+                v.release();
+                v = w;
+            }
+        }
         t->level_off.push_back(o);
         t->nodes = o;
         t->maxfreq = st.sp.mf;
@@ -4453,6 +4503,7 @@ struct dsm_server {
     // the reader sets of its EARLIER siblings, all final once every stream is past the node -- a shallow pass over the parent's
     // children with the parent's order as its seed, remembered (a node's order never changes afterwards).
     std::map<std::vector<dsm::u8>, std::vector<dsm::u16>> orders;
+    dsm::ServerEngines engines;
     int order_of(const std::vector<dsm::u8>& path, dsm_trie* const* hol, bool wide, const std::string& chain, std::vector<dsm::u16>* out) {
         using namespace dsm;
         auto f = orders.find(path);
@@ -4468,7 +4519,7 @@ struct dsm_server {
             seed.ord.push_back(po);
             sp = &seed;
         }
-        if (int r = server_run(wide, hol, d, prm, chain + text_of(parent), sink, ctx, false, 1, ~0u, cap.depth, sp, &cap, nullptr)) return r;
+        if (int r = server_run(wide, hol, d, prm, chain + text_of(parent), sink, ctx, false, 1, ~0u, cap.depth, sp, &cap, nullptr, &engines, 1)) return r;
         size_t q = 0;
         while (q < cap.sym.size() && cap.sym[q] != (u32)path.back()) ++q;
         if (q == cap.sym.size()) return fail(DSM_E_HIP, "dsm_server: the shallow pass did not find the node " + chain + text_of(path));
@@ -4517,10 +4568,10 @@ struct dsm_server {
         seed.ord.emplace_back();
         r = order_of(path, hol.data(), wide, chain, &seed.ord[0]);
         if (!r && is_unit) {
-            r = server_run(wide, unit.data(), d, prm, full, sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);
+            r = server_run(wide, unit.data(), d, prm, full, sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);  // (an engine of the unit's size, for this run)
             if (!r) { add_stats(a, a.union_nodes >= (u64)(U - 1) ? a.union_nodes - (u64)(U - 1) : 0); ++units_merged; if (nodes > peak_unit_nodes) peak_unit_nodes = nodes; }
         } else if (!r) {
-            r = server_run(wide, hol.data(), d, prm, full, sink, ctx, true, depth, depth, depth + 1, &seed, nullptr, &a);
+            r = server_run(wide, hol.data(), d, prm, full, sink, ctx, true, depth, depth, depth + 1, &seed, nullptr, &a, &engines, 1);
             if (!r) add_stats(a, 1);
         }
         cleanup();
@@ -4545,7 +4596,7 @@ struct dsm_server {
         dsm_stats a;
         memset(&a, 0, sizeof a);
         if (!r && !chain.empty()) {
-            r = server_run(wide, hol.data(), d, prm, chain, sink, ctx, true, 1, (u32)K, (u32)K + 1, nullptr, nullptr, &a);
+            r = server_run(wide, hol.data(), d, prm, chain, sink, ctx, true, 1, (u32)K, (u32)K + 1, nullptr, nullptr, &a, &engines, 1);
             if (!r) add_stats(a, (u64)K);
         }
         for (auto* t : hol) if (t) dsm_trie_free(t);
