@@ -4218,7 +4218,7 @@ static int server_run_t(dsm_trie* const* tr, int n, const dsm_params& q, const s
         m = own.get();
         int rc;
         if (keep) {
-            const u64 cap = need * 2 > min_cap ? need * 2 : min_cap;
+            const u64 cap = need + need / 8 > min_cap ? need + need / 8 : min_cap;  // (a little room: the next units are about this size)
             std::vector<dsm_trie> ph(n);
             std::vector<dsm_trie*> pp(n);
             for (int k = 0; k < n; ++k) { ph[k].device = tr[k]->device; ph[k].nodes = cap; pp[k] = &ph[k]; }
@@ -4568,7 +4568,10 @@ struct dsm_server {
         seed.ord.emplace_back();
         r = order_of(path, hol.data(), wide, chain, &seed.ord[0]);
         if (!r && is_unit) {
-            r = server_run(wide, unit.data(), d, prm, full, sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a);  // (an engine of the unit's size, for this run)
+            // (small units share one engine, whose buffers then stay; a large unit gets an engine of its size that goes with it)
+            u64 biggest = 0;
+            for (auto* t : unit) biggest = t->nodes > biggest ? t->nodes : biggest;
+            r = server_run(wide, unit.data(), d, prm, full, sink, ctx, true, U, ~0u, ~0u, &seed, nullptr, &a, &engines, biggest <= (1u << 25) ? 2 : 0);
             if (!r) { add_stats(a, a.union_nodes >= (u64)(U - 1) ? a.union_nodes - (u64)(U - 1) : 0); ++units_merged; if (nodes > peak_unit_nodes) peak_unit_nodes = nodes; }
         } else if (!r) {
             r = server_run(wide, hol.data(), d, prm, full, sink, ctx, true, depth, depth, depth + 1, &seed, nullptr, &a, &engines, 1);
