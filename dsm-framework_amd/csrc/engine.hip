@@ -4614,29 +4614,22 @@ struct dsm_server {
                 for (;;) {
                     if (quit || rc) return;
                     // the first event, in the post-order of the union trie, among the streams' next ones -- ready when no stream can still
-                    // produce it or one before it
-                    have = false;
-                    all_ended = true;
-                    for (int k = 0; k < d; ++k) {
-                        Stream& st = *s[k];
-                        std::lock_guard<std::mutex> sl(st.mu);
-                        all_ended = all_ended && st.ended;
-                        if (st.taken < st.sp.events.size()) {
-                            const std::vector<dsm::u8>& p = st.sp.events[st.taken].path;
-                            if (!have || dsm::post_before(p, ev)) { ev = p; have = true; }
+                    // produce it or one before it (pick_event, stream_parse.h); every stream is held while they are looked at together
+                    {
+                        std::vector<std::unique_lock<std::mutex>> held;
+                        std::vector<const dsm::StreamParser*> sps;
+                        std::vector<size_t> taken;
+                        std::vector<bool> ended;
+                        all_ended = true;
+                        for (int k = 0; k < d; ++k) {
+                            held.emplace_back(s[k]->mu);
+                            sps.push_back(&s[k]->sp); taken.push_back(s[k]->taken); ended.push_back(s[k]->ended);
+                            all_ended = all_ended && s[k]->ended;
                         }
-                    }
-                    if (have) {
-                        bool ready = true;
-                        for (int k = 0; k < d && ready; ++k) {
-                            Stream& st = *s[k];
-                            std::lock_guard<std::mutex> sl(st.mu);
-                            const bool mine = st.taken < st.sp.events.size() && st.sp.events[st.taken].path == ev;
-                            ready = mine || st.ended || !st.sp.may_produce(ev);
-                        }
-                        if (ready) break;
-                    } else if (all_ended) {
-                        break;
+                        const dsm::EventPick pk = dsm::pick_event(sps, taken, ended);
+                        have = pk.have;
+                        if (pk.have && pk.ready) { ev = pk.path; break; }
+                        if (!pk.have && all_ended) break;
                     }
                     cv.wait(lk);
                 }

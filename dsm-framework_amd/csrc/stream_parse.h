@@ -192,6 +192,30 @@ private:
     }
 };
 
+// What a server merging while it receives does next (dsm_server, engine.hip): among the streams' next unprocessed events the first one in
+// the post-order of the union trie; it is due (`ready`) when every stream either lists it as ITS next event, has ended, or can no
+// longer produce it or anything before it.  taken[k]: events of stream k already processed.  (Host logic without a device:
+// tests/native/server_sched_check.cpp drives it over the reference streams in random interleavings.)
+struct EventPick {
+    bool have = false, ready = false;
+    std::vector<u8> path;
+};
+inline EventPick pick_event(const std::vector<const StreamParser*>& sp, const std::vector<size_t>& taken, const std::vector<bool>& ended) {
+    EventPick pk;
+    for (size_t k = 0; k < sp.size(); ++k)
+        if (taken[k] < sp[k]->events.size()) {
+            const std::vector<u8>& p = sp[k]->events[taken[k]].path;
+            if (!pk.have || post_before(p, pk.path)) { pk.path = p; pk.have = true; }
+        }
+    if (!pk.have) return pk;
+    pk.ready = true;
+    for (size_t k = 0; k < sp.size() && pk.ready; ++k) {
+        const bool mine = taken[k] < sp[k]->events.size() && sp[k]->events[taken[k]].path == pk.path;
+        pk.ready = mine || ended[k] || !sp[k]->may_produce(pk.path);
+    }
+    return pk;
+}
+
 // the whole stream at once: every level stays on the host
 inline int parse_client_stream(const u8* p, size_t n, std::vector<HostTrieLevel>& L, u64* nodes, u64* maxfreq) {
     StreamParser sp;

@@ -146,3 +146,39 @@ def _run_units(exe, tmp_path, body, piece, unit_depth, chain_len):
     p.write_bytes(body)
     r = subprocess.run([exe, str(p), str(piece), str(unit_depth), str(chain_len)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return r.returncode, r.stdout.decode().strip(), r.stderr.decode()
+
+
+def test_server_takes_the_subtrees_in_union_post_order_and_never_early(golden, tmp_path_factory, tmp_path):
+    """The merger of dsm_server (merging while receiving): which subtree is due next is host logic over the streams' decoders
+    (dsm::pick_event).  The three reference streams of a prefix are fed in random pieces and interleavings; every event is taken
+    once, in the post-order of the union trie, and none before every stream is past it (checked against a complete first parse)."""
+    exe = str(tmp_path_factory.mktemp("native") / "server_sched_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "server_sched_check.cpp")], check=True)
+    names = golden.manifest["sets"]["toy3"]["names"]
+    for prefix in ("A", "GT", "TTG"):
+        files = []
+        for n in names:
+            f = tmp_path / ("%s.%s.bin" % (n, prefix))
+            f.write_bytes(_body(golden.stream("toy3", n, prefix)))
+            files.append(str(f))
+        K = len(prefix)
+        for extra in (0, 1, 2):
+            for seed in (1, 2, 3):
+                r = subprocess.run([exe, str(K), str(K + 1 + extra), str(seed)] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                out = r.stdout.decode().strip()
+                assert r.returncode == 0 and out.startswith("ok "), (prefix, extra, seed, out, r.stderr.decode()[-500:])
+                f = dict(kv.split("=") for kv in out.split()[1:])
+                assert int(f["units"]) >= 1 and int(f["events"]) >= int(f["units"])
+                if prefix == "A":
+                    assert int(f["early"]) >= 1, out      # something is merged before the last stream has ended
+    # a sample without the prefix (empty stream) and one that holds a single subtree of it
+    files = []
+    for n, p in ((names[0], "A"), (names[1], "AC")):
+        f = tmp_path / ("%s.%s.mix.bin" % (n, p))
+        f.write_bytes(_body(golden.stream("toy3", n, p)))
+        files.append(str(f))
+    e = tmp_path / "empty.bin"
+    e.write_bytes(b"")
+    r = subprocess.run([exe, "1", "3", "7", files[0], str(e), files[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout.decode().startswith("ok "), (r.stdout, r.stderr.decode()[-500:])
