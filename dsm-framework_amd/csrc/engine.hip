@@ -155,6 +155,13 @@ constexpr int REC_FIELDS = 10;
 template <typename P>
 __host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
 constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
+// One sample: the exact entropy test of the reference (metaserver.cpp:379-413) depends on the node's frequency alone -- with one reader
+// the entropy is rounding noise around 0, and whether it is below emin decides -- so the host tabulates its verdict,
+// computed with its own libm expression, for every frequency below KEEP_FREQS, one bit each, BEHIND the counters (no extra kernel
+// argument), and the LF-step kernel's candidate ballot reads it: what reaches the host is final, nothing is dropped there any more
+// and the tuples go to the sink from the pinned buffers they arrived in.  (Larger frequencies -- a few nodes at the top -- are kept
+// and decided by the host as before.)
+constexpr u32 KEEP_FREQS = 1u << 22;
 constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=record bytes read + written [5]=records read
 constexpr u32 DEAD = 0xFFFFFFFFu;
 constexpr u32 PACK_FMAX = 512;        // a level whose frequencies are all below this packs frequency and flags of a node into 16 bits
@@ -380,7 +387,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                             u8* __restrict__ pl, const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile,
                                             const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
-                                            const u64* __restrict__ pplane = nullptr, SelfState* ss = nullptr) {
+                                            const u64* __restrict__ pplane = nullptr, SelfState* ss = nullptr, const u32* __restrict__ keeptab = nullptr) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
     const size_t cap = a.cap;
@@ -391,6 +398,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const P sp = nd.sp, ep = nd.ep;
     const u32 emask = nd.emask;
     const u32 ne = __popc(emask);
+    u32 keepw = ~0u;  // the word of the keep table that holds this node's frequency (requested here, used at the candidate ballot)
+    const u64 freq1 = (u64)ep - (u64)sp + 1;
+    if (!SELF) keepw = keeptab[(freq1 < KEEP_FREQS ? (u32)freq1 : 0u) >> 5];
     const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;  // blocks of the two interval ends
     u32 n_lf = 0, n_rank = 0, lines = 0;
     P Rsp[4], Rep[4];
@@ -519,7 +529,8 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
     if (a.symbol_phase & 8u) {  // one sample: planes and the level's candidates in one line per tile (the advance sweep reads it)
         // metaserver.cpp:406-419 for a node with one reader: not a single child (416-417), no single left char (383-387, 418)
-        const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u));
+        const bool ekeep = SELF || freq1 >= KEEP_FREQS || ((keepw >> ((u32)freq1 & 31u)) & 1u);  // the exact entropy verdict for this frequency
+        const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u) && ekeep);
         if (lane < 6) {
             const u64 nc = (u64)__popcll(cb);
             const u64 word = lane < 4 ? DSM_PICK(bal, lane) : (lane == 4 ? cb : (nc | (nc << 32)));
@@ -623,6 +634,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const u32 t0 = gw;
     const u32 ntile = (a.F + 63) >> 6;
+    const u32* keeptab = reinterpret_cast<const u32*>(counters + (size_t)COUNTER_SHARDS * 8);  // (see KEEP_FREQS)
     ExpandAcc acc;
 #ifdef DSM_CLOCK_PROBE
     const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
@@ -647,9 +659,9 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         load_head<P>(rec, a.cap, r0, hA);
         // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
         for (u32 t = t0; t < ntile; t += 2 * nwaves) {
-            expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, pplane, &ss);
+            expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, pplane, &ss, keeptab);
             if (t + nwaves < ntile)
-                expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss);
+                expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss, keeptab);
         }
     }
 #ifdef DSM_CLOCK_PROBE
@@ -2202,13 +2214,22 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
     const u64 W = cnt_t[nth], PW = cnt_p[nth], QW = cnt_q[nth];
     u32* o_path = (u32*)E.out[0].ensure((W + 1) * 4);
     u32* o_pair = (u32*)E.out[1].ensure((W + 1) * 4);
-    double* o_ent = (double*)E.out[2].ensure(W * 8 + 8);
-    char* o_paths = (char*)E.out[3].ensure(PW + 1);
-    u32* o_ids = (u32*)E.out[4].ensure(QW * 4 + 4);
-    u64* o_freqs = (u64*)E.out[5].ensure(QW * 8 + 8);
+    // Nothing dropped (one sample: the device applied the exact entropy verdict already, see KEEP_FREQS): the tuples stay where the
+    // copy engine put them -- only the offsets are rebased to the chunk -- instead of being moved together (3.9 GB per pass at the
+    // benchmark size, 4-15 ms of a pass's 180 and most of its run-to-run spread).
+    const bool in_place = W == nt;
+    double* o_ent = in_place ? ent : (double*)E.out[2].ensure(W * 8 + 8);
+    char* o_paths = in_place ? const_cast<char*>(paths) + path_off[t_lo] : (char*)E.out[3].ensure(PW + 1);
+    u32* o_ids = in_place ? const_cast<u32*>(ids) + pair_off[t_lo] : (u32*)E.out[4].ensure(QW * 4 + 4);
+    u64* o_freqs = in_place ? const_cast<u64*>(freqs) + pair_off[t_lo] : (u64*)E.out[5].ensure(QW * 8 + 8);
     auto pass2 = [&](unsigned t) {
         u32 lo, hi;
         range(t, lo, hi);
+        if (in_place) {
+            const u32 pb0 = path_off[t_lo], qb0 = pair_off[t_lo];
+            for (u32 r = lo; r < hi; ++r) { o_path[r - t_lo] = path_off[r] - pb0; o_pair[r - t_lo] = pair_off[r] - qb0; }
+            return;
+        }
         u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
         for (u32 r = lo; r < hi; ++r) {
             if (!keep[r - t_lo]) continue;
@@ -2744,7 +2765,21 @@ class Engine {
         if (int rc = dalloc(cand_wsum, nwave + 8)) return rc;
         if (int rc = dalloc(cand_wscan, nwave + 8)) return rc;
         if (int rc = dalloc(scan_tmp64, scan_tmp_elems(nwave) + 8)) return rc;
-        if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8)) return rc;
+        if (int rc = dalloc(d_counters, (size_t)COUNTER_SHARDS * 8 + KEEP_FREQS / 64)) return rc;
+        {   // the keep table behind the counters (see KEEP_FREQS): the emitter's own expression (emit_job), for d = 1
+            std::vector<u32> kt(KEEP_FREQS / 32, ~0u);
+            if (d == 1 && !trie_mode && prm.emax > 0) {
+                const double* terms = term_table();
+                const double* logn = logn_table();
+                for (u32 f = 0; f < KEEP_FREQS; ++f) {
+                    const u64 sumN = 1ull + f;
+                    const double sl = f < TERM_TAB ? terms[f] : (double)((u64)f + 1) * log((double)((u64)f + 1)) / LN2;
+                    const double e = (sumN < LOGN_TAB ? logn[sumN] : log((double)sumN) / LN2) - sl / (double)sumN;
+                    if (e < prm.emin || e > prm.emax) kt[f >> 5] &= ~(1u << (f & 31));
+                }
+            }
+            DSM_HIP(hipMemcpy(d_counters + (size_t)COUNTER_SHARDS * 8, kt.data(), kt.size() * sizeof(u32), hipMemcpyHostToDevice));
+        }
         if (int rc = dalloc(d_totals, 8)) return rc;
         if (int rc = dalloc(d_totals64, 4)) return rc;
         if (int rc = dalloc(d_pub_tot, 8)) return rc;

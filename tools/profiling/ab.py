@@ -15,17 +15,17 @@ if not os.path.exists(path):
     codes = builder.synth_reads(42, reads, 100, reads * 5, 0.005, device="cuda")
     builder.build_from_codes(codes, path + ".tmp"); del codes; torch.cuda.empty_cache(); os.replace(path + ".tmp", path)
 ix = pydsm.Index(path, device=0)
-h = hashlib.sha256()
-cnt = [0]
+hp, hl, hf = hashlib.sha256(), hashlib.sha256(), hashlib.sha256()   # paths, lengths, frequencies: each over the whole prefix, so that
+cnt = [0]                                                            # the hash does not depend on where the batches are cut
 def on_batch(b):
     n = int(b.ntuples); cnt[0] += n
     po = np.ctypeslib.as_array(b.path_off, shape=(n + 1,)); qo = np.ctypeslib.as_array(b.pair_off, shape=(n + 1,))
-    h.update(np.ctypeslib.as_array(ctypes.cast(b.path_bytes, ctypes.POINTER(ctypes.c_uint8)), shape=(int(po[-1]),)).tobytes())
-    h.update(np.diff(po).astype(np.uint32).tobytes())
-    h.update(np.ctypeslib.as_array(b.freqs, shape=(int(qo[-1]),)).tobytes())
+    hp.update(np.ctypeslib.as_array(ctypes.cast(b.path_bytes, ctypes.POINTER(ctypes.c_uint8)), shape=(int(po[-1]),)).tobytes())
+    hl.update(np.diff(po).astype(np.uint32).tobytes())
+    hf.update(np.ctypeslib.as_array(b.freqs, shape=(int(qo[-1]),)).tobytes())
 with pydsm.Miner([ix], fmin=10, pmin=1, emax=2.0) as m:
     _, st = m.mine_many(["G"], text=False, on_batch=on_batch)
-    print("parity G: tuples %d nodes %d sha %s" % (cnt[0], st.reported, h.hexdigest()[:16]))
+    print("parity G: tuples %d nodes %d sha %s" % (cnt[0], st.reported, hashlib.sha256(hp.digest() + hl.digest() + hf.digest()).hexdigest()[:16]))
     m.mine_many(["A", "C", "G", "T"], text=False)
     best = None
     for r in range(reps):
