@@ -232,6 +232,11 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
     except Exception as e:  # noqa: BLE001
         out.append({"record": "wire-stream mode", "error": repr(e)})
     note("wire-stream mode done")
+    try:  # f2, the server side (metaserver.cpp:682-739): four clients' streams of prefix A, fed by four threads, merged WHILE they arrive
+        out.append(server_record(args, dev, local, pydsm))
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "server side (merge while receiving)", "error": repr(e)})
+    note("server side done")
     try:
         a8 = argparse.Namespace(**vars(args))
         a8.gpus, a8.nlocal = 1, 8
@@ -290,6 +295,72 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
     except Exception as e:  # noqa: BLE001
         out.append({"record": "4-Gbase samples (configs[3])", "error": repr(e)})
     return out
+
+
+def server_record(args, dev, local, pydsm):
+    """Four read sets of a tenth of the benchmark's size each; their clients' wire streams for prefix A (our own client: byte-identical to
+    the reference's) are fed in 1 MB pieces by four threads into dsm_server -- once merged after the last stream has ended (what
+    round 2's server did), once merged while they arrive in 16 subtrees.  Tuples are identical; the record is the second run."""
+    import threading
+    import torch
+    from pydsm import builder
+    reads = max(100_000, args.reads // 10)
+    streams = []
+    for s_ in range(4):
+        pth = os.path.join(args.workdir, "srv-%d.s%d_r%d_l%d.fmi" % (s_, 200 + s_, reads, args.rlen))
+        if not os.path.exists(pth):
+            codes = builder.synth_reads(200 + s_, reads, args.rlen, reads * 5, args.sub_rate, device=dev, private_frac=0.05)
+            builder.build_from_codes(codes, pth + ".tmp")
+            del codes
+            os.replace(pth + ".tmp", pth)
+        ixs = pydsm.Index(pth, device=local)
+        with pydsm.Miner([ixs], fmin=args.fmin, stream_mode=True) as m:
+            streams.append(m.enumerate("A", with_header=False)[0])
+        ixs.close()
+    torch.cuda.empty_cache()
+
+    def run(prefix_len, unit_extra):
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        low, stop = [free0], [False]
+
+        def sampler():
+            while not stop[0]:
+                low[0] = min(low[0], torch.cuda.mem_get_info()[0])
+                time.sleep(0.002)
+        srv = pydsm.Server(len(streams), prefix_len=prefix_len, unit_extra=unit_extra, pmin=2, emax=args.emax, text=False)
+        ts = threading.Thread(target=sampler)
+        ts.start()
+        t0 = time.perf_counter()
+
+        def reader(i):
+            b = streams[i]
+            for o in range(0, len(b), 1 << 20):
+                srv.feed(i, b[o:o + (1 << 20)])
+            srv.end(i)
+        ths = [threading.Thread(target=reader, args=(i,)) for i in range(len(streams))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        t1 = time.perf_counter()
+        _, st = srv.finish()
+        t2 = time.perf_counter()
+        stop[0] = True
+        ts.join()
+        units = srv.units()[0]
+        srv.close()
+        return {"feed_s": t1 - t0, "after_last_byte_s": t2 - t1, "tuples": st.tuples, "union_nodes": st.union_nodes, "units": units,
+                "device_peak_mb": (free0 - low[0]) / 1e6}
+    at_end = run(None, 0)
+    live = run(1, 1)
+    tot = live["feed_s"] + live["after_last_byte_s"]
+    return {"record": "server side: 4 client streams of %.0f MB each (prefix A of 4 read sets of %d x %d bp) fed by 4 threads into dsm_server, merged "
+                      "while they arrive (16 subtrees)" % (len(streams[0]) / 1e6, reads, args.rlen),
+            "value": live["union_nodes"] / tot, "unit": "merged nodes/s", "ms_per_step": tot * 1e3, "union_nodes": live["union_nodes"],
+            "tuples": live["tuples"], "subtrees_merged_while_receiving": live["units"], "seconds_after_the_last_byte": live["after_last_byte_s"],
+            "device_memory_peak_mb": live["device_peak_mb"], "device_memory_peak_mb_when_merged_at_the_end": at_end["device_peak_mb"],
+            "tuples_when_merged_at_the_end": at_end["tuples"], "stream_bytes": int(sum(len(b) for b in streams)), "dtype": "u32"}
 
 
 def main():
