@@ -1,3 +1,5 @@
+# Instruction counts by class and wave residency of the LF-step kernel (profiles/r03_lf_bound.txt, sections 1-2): one rocprofv3 --pmc
+# pass of the default bench command.  usage: bash tools/profiling/pmc_insts.sh [tag]   (DSM_LIB_PATH picks a library variant)
 R=$GRAFT_REPO_ROOT
 TAG=${1:-new}
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,7 @@
+# Memory-side counters of the LF-step kernel (profiles/r03_lf_bound.txt, section 1): TCP->TCC read / write latency, vector-memory
+# instruction counts, TA FIFO stalls, one rocprofv3 --pmc pass per group of the default bench command (no trace domains combined with
+# --pmc).  The UTCL1 and TA_BUSY groups are refused by this rocprofv3 build ("fail ..." is printed and the pass skipped).
+# usage: bash tools/profiling/pmc_latency.sh [tag]   (DSM_LIB_PATH picks a library variant)
 R=$GRAFT_REPO_ROOT
 TAG=${1:-base}
 cd /tmp && export TMPDIR=/tmp
