@@ -2181,6 +2181,10 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
     const char* paths = (const char*)E.pin[4].p;
     double* ent = (double*)E.ent_all.ensure((size_t)nt * 8);
     u8* keep = (u8*)E.keep.ensure(nt);
+    // (offsets rebased to the chunk are written along with the verdicts: they are the batch's offsets if every tuple is kept)
+    u32* o_path = (u32*)E.out[0].ensure(((size_t)nt + 1) * 4);
+    u32* o_pair = (u32*)E.out[1].ensure(((size_t)nt + 1) * 4);
+    const u32 pb0 = path_off[t_lo], qb0 = pair_off[t_lo];
     unsigned nth = host_threads();
     if (nt < 65536) nth = 1;
     const u32 per = (nt + nth - 1) / nth;
@@ -2202,6 +2206,8 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
             }
             double e = (sumN < LOGN_TAB ? logn[sumN] : log((double)sumN) / LN2) - sumNlogN / (double)sumN;
             ent[r - t_lo] = e;
+            o_path[r - t_lo] = path_off[r] - pb0;
+            o_pair[r - t_lo] = pair_off[r] - qb0;
             bool k = !(emax > 0 && (e < emin || e > emax));
             keep[r - t_lo] = k;
             if (k) { ++kt; kp += path_off[r + 1] - path_off[r]; kq += pair_off[r + 1] - pair_off[r]; }
@@ -2212,8 +2218,6 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
     run_all(pass1);
     for (unsigned t = 0; t < nth; ++t) { cnt_t[t + 1] += cnt_t[t]; cnt_p[t + 1] += cnt_p[t]; cnt_q[t + 1] += cnt_q[t]; }
     const u64 W = cnt_t[nth], PW = cnt_p[nth], QW = cnt_q[nth];
-    u32* o_path = (u32*)E.out[0].ensure((W + 1) * 4);
-    u32* o_pair = (u32*)E.out[1].ensure((W + 1) * 4);
     // Nothing dropped (one sample: the device applied the exact entropy verdict already, see KEEP_FREQS): the tuples stay where the
     // copy engine put them -- only the offsets are rebased to the chunk -- instead of being moved together (3.9 GB per pass at the
     // benchmark size, 4-15 ms of a pass's 180 and most of its run-to-run spread).
@@ -2225,11 +2229,6 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
     auto pass2 = [&](unsigned t) {
         u32 lo, hi;
         range(t, lo, hi);
-        if (in_place) {
-            const u32 pb0 = path_off[t_lo], qb0 = pair_off[t_lo];
-            for (u32 r = lo; r < hi; ++r) { o_path[r - t_lo] = path_off[r] - pb0; o_pair[r - t_lo] = pair_off[r] - qb0; }
-            return;
-        }
         u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
         for (u32 r = lo; r < hi; ++r) {
             if (!keep[r - t_lo]) continue;
@@ -2241,7 +2240,7 @@ static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, doubl
             ++w; pw += pl; qw += ql;
         }
     };
-    run_all(pass2);
+    if (!in_place) run_all(pass2);
     o_path[W] = (u32)PW;
     o_pair[W] = (u32)QW;
     clock_gettime(CLOCK_MONOTONIC, &t1);
