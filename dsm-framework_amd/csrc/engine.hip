@@ -36,91 +36,9 @@
 #include "scan.h"
 #include "setorder.h"
 #include "stream_parse.h"
+#include "lfstep.h"
 
 namespace dsm {
-
-// ---------------------------------------------------------------------------------------------
-// rank on the bit-plane blocks
-// ---------------------------------------------------------------------------------------------
-#define DSM_PICK(a, c) ((c) == 0 ? (a)[0] : ((c) == 1 ? (a)[1] : ((c) == 2 ? (a)[2] : (a)[3])))
-
-// occurrences of A,C,G,T among the first `off` symbols of a block with four population counts:
-// |base|, |base & p1| = G+T, |base & p0| = C+T, |base & p1 & p0| = T
-__device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4]) {
-    u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
-    u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
-    u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
-    u64 h1a = ba & r.p1a, h1b = bb & r.p1b;
-    u32 tot = __popcll(ba) + __popcll(bb);
-    u32 s1 = __popcll(h1a) + __popcll(h1b);
-    u32 s0 = __popcll(ba & r.p0a) + __popcll(bb & r.p0b);
-    u32 s3 = __popcll(h1a & r.p0a) + __popcll(h1b & r.p0b);
-    out[3] = s3; out[2] = s1 - s3; out[1] = s0 - s3; out[0] = tot - s1 - s0 + s3;
-}
-
-// Superblock bases (C[c] + occurrences of c before the superblock).  An index below 2^31 symbols has one superblock:
-// its four bases travel as kernel arguments (scalar registers).  Larger indexes keep the table in LDS (sbl): a read of it
-// is an LDS access, which does not queue behind the global prefetches the way a global load would.  The choice is a template
-// parameter (ONESB), not a run-time select: selecting between the argument block and memory turns every access into a flat
-// load, whose wait also drains every prefetch in flight.
-struct SbArgs {
-    u64 sb0[4];
-};
-constexpr u32 SB_LDS_MAX = 64;  // superblocks the LDS copy holds (2^37 symbols)
-
-// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
-template <typename P, bool ONESB>
-__device__ __forceinline__ void rank4_blk(const SbArgs& sa, const u64* sbl, const Blk16& r, u64 x, P out[4]) {
-    u32 c4[4];
-    blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = (P)((ONESB ? sa.sb0[c] : sbl[(x >> SB_SHIFT) * 4 + c]) + r.cnt[c] + c4[c]);
-}
-
-// LF(c, x-1) for one base chosen per lane (c = 0..3), on the plane words of a block; cntc = the block's count of that base.
-// A plane is taken as it is or inverted, so the base needs no branch.
-template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a, u64 p0b, u64 p1a, u64 p1b, u64 p2a, u64 p2b, u32 cntc, u64 x, u32 c) {
-    const u32 off = (u32)(x & (BLK_SYMS - 1));
-    const u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
-    const u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
-    const u64 i0 = (c & 1u) ? 0ull : ~0ull, i1 = (c & 2u) ? 0ull : ~0ull;
-    const u64 xa = ma & ~p2a & (p1a ^ i1) & (p0a ^ i0);
-    const u64 xb = mb & ~p2b & (p1b ^ i1) & (p0b ^ i0);
-    const u64 base = ONESB ? DSM_PICK(sa.sb0, c) : sbl[(x >> SB_SHIFT) * 4 + c];
-    return (P)(base + cntc + (u32)(__popcll(xa) + __popcll(xb)));
-}
-
-// The index blocks of a tile are staged in LDS.  The intervals of a tile's nodes are disjoint and increase along the lanes, so
-// the blocks the lanes need (block of sp, block of ep + 1) form a non-decreasing sequence: the distinct ones -- about 0.7 per node
-// in the wide levels, where neighbouring nodes share blocks -- are numbered by two ballots, their numbers listed in LDS, and
-// fetched by groups of four lanes, one 16-byte quarter each: a block is ONE 64-byte request of one load instruction instead of
-// four quarter requests in four instructions, repeated by every lane that shares it.  (The kernel is bound by the requests its
-// waves issue, not by bytes.)  Word w of the staging area = quarter w & 3 of distinct block w >> 2; lanes then read the blocks
-// they need -- for the four-base ranks and again for the left-extension ranks -- from there.
-constexpr u32 STAGE_BLOCKS = 128;                        // distinct blocks of a tile: at most two per lane
-constexpr u32 WAVE_LDS_WORDS = STAGE_BLOCKS * 4 + 32;    // uint4 per wave: the staged blocks, then the list of their numbers (8.5 KB)
-__device__ __forceinline__ void staged_blk(const uint4* wl, u32 idx, Blk16& r) {
-    const uint4 h = wl[idx * 4 + 0], a = wl[idx * 4 + 1], c = wl[idx * 4 + 2], d = wl[idx * 4 + 3];
-    r.cnt[0] = h.x; r.cnt[1] = h.y; r.cnt[2] = h.z; r.cnt[3] = h.w;
-    r.p0a = ((u64)a.y << 32) | a.x; r.p0b = ((u64)a.w << 32) | a.z;
-    r.p1a = ((u64)c.y << 32) | c.x; r.p1b = ((u64)c.w << 32) | c.z;
-    r.p2a = ((u64)d.y << 32) | d.x; r.p2b = ((u64)d.w << 32) | d.z;
-}
-template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 idx, u64 x, u32 c) {
-    const uint4 q1 = wl[idx * 4 + 1], q2 = wl[idx * 4 + 2], q3 = wl[idx * 4 + 3];
-    const u32 cntc = reinterpret_cast<const u32*>(wl + idx * 4)[c];
-    return rank_one<P, ONESB>(sa, sbl, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z, ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z,
-                              ((u64)q3.y << 32) | q3.x, ((u64)q3.w << 32) | q3.z, cntc, x, c);
-}
-// the same from memory (positions outside the two blocks a lane holds: intervals over more than two blocks only)
-template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_load(const DevIndex& ix, const SbArgs& sa, const u64* sbl, u64 x, u32 c) {
-    Blk16 b;
-    load_blk(ix.blk, x >> BLK_SHIFT, b);
-    return rank_one<P, ONESB>(sa, sbl, b.p0a, b.p0b, b.p1a, b.p1b, b.p2a, b.p2b, DSM_PICK(b.cnt, c), x, c);
-}
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #pragma unroll
@@ -128,44 +46,6 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     return v;
 }
 
-// Records (EnumerateQuery.h:44-45, Query.h:110-111): the interval [sp, ep] of a node in the sample and its non-empty
-// left-extension intervals, kept in base order in the first popcount(mask) of four slots (mask bit a: the interval of base a
-// is non-empty).  Records are addressed through a handle per frontier node (rp[v]); DEAD = the node is absent from this sample.
-// Two formats, chosen per level:
-//   wide (struct of arrays)  field f of record r lives at rec[f * cap + r]: 0 sp, 1 ep, 2 + 2e / 3 + 2e = min / max of slot e,
-//                            followed by one mask byte per record.  Used while frequencies may reach 65535 (the top few levels
-//                            of a prefix) and, in every level, for slots 2 and 3 (fewer than one node in a hundred has them).
-//   compact                  one 16-byte word per record (32 bytes with 64-bit positions): sp, then 16-bit ep - sp and the
-//                            offsets from sp of the ends of slots 0 and 1, then the mask.  A level is compact when every frequency
-//                            of its parent level is below 65535.  One load / one store per record instead of seven: the LF-step
-//                            kernel is bound by the memory transactions it issues, not by their bytes.  The words share the
-//                            memory of fields 0-3 of the wide format (a level has one format).
-//
-// Order of a level.  The nodes of a level are kept in COLEX order of their paths (sorted by the reversed substring), not in
-// trie order.  The index holds reversed reads, so the suffix-array interval of a substring P is ordered by reverse(P):
-// colex order of the union level IS increasing sp order in every sample.  Neighbouring lanes of the LF-step kernel therefore
-// read neighbouring records and neighbouring (often the same) index blocks, and write neighbouring column entries.
-// LF is monotone, so the children with symbol c of colex-ordered parents are colex-ordered among themselves and every
-// c = A child precedes every c = C child ...: the next level is the stable 4-way partition A|C|G|T of the children, and a
-// child's place is a prefix count over its symbol's bit plane -- no atomics, no allocation that can overflow.
-//   record handle of child (u, c) in a sample = c * seg + 64 * (u / 64) + rank of u among its wave's parents with a child c
-// (every wave of 64 parents owns 64 handles per symbol: at most one child per symbol and parent).  The trie order the
-// reference prints in is recovered at the end of a prefix from the retained parent links, as before.
-constexpr int REC_FIELDS = 10;
-template <typename P>
-__host__ __device__ constexpr size_t rec_elems(size_t cap) { return (size_t)REC_FIELDS * cap + (cap + sizeof(P) - 1) / sizeof(P); }
-constexpr int COUNTER_SHARDS = 1024;  // power of two; each shard is one 64-byte line
-// One sample: the exact entropy test of the reference (metaserver.cpp:379-413) depends on the node's frequency alone -- with one reader
-// the entropy is rounding noise around 0, and whether it is below emin decides -- so the host tabulates its verdict,
-// computed with its own libm expression, for every frequency below KEEP_FREQS, one bit each, BEHIND the counters (no extra kernel
-// argument), and the LF-step kernel's candidate ballot reads it: what reaches the host is final, nothing is dropped there any more
-// and the tuples go to the sink from the pinned buffers they arrived in.  (Larger frequencies -- a few nodes at the top -- are kept
-// and decided by the host as before.)
-constexpr u32 KEEP_FREQS = 1u << 22;
-constexpr int NCOUNTERS = 6;          // [0]=reported [1]=lf_steps [2]=rank_ops [3]=index lines fetched [4]=record bytes read + written [5]=records read
-constexpr u32 DEAD = 0xFFFFFFFFu;
-constexpr u32 PACK_FMAX = 512;        // a level whose frequencies are all below this packs frequency and flags of a node into 16 bits
-constexpr u32 TILE = 256;             // parents per block of the expand / advance kernels
 
 // Children directory of a level ("kids"): per 64 nodes (one wave) four bit planes -- bit j of plane c: node 64w + j has a child
 // with symbol c in the union trie -- and four counts cum[c] = index, in the next level, of the first such child of the wave.
@@ -214,541 +94,6 @@ __device__ __forceinline__ u32 xcd_block() {
 constexpr int NPT = 4;
 static inline dim3 grid_npt(u64 n) { return dim3((unsigned)((n + 256ull * NPT - 1) / (256ull * NPT))); }
 
-
-struct ExpandArgs {
-    u32 F;            // frontier width
-    u32 cap;          // record capacity (stride of both record buffers) = 4 * seg
-    u32 seg;          // handles per symbol segment (>= F rounded up to a tile)
-    u32 nbp;          // tiles of the level = stride of cnt4
-    u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
-    u32 fmin;
-    u32 symbol_phase; // bit 0: node is handled by nextSymbol (size-1 nodes take followOneBranch); bit 1: the children count as reported;
-                      // bit 2 (one sample): the level's nodes are tested for output here -- everything in metaserver.cpp:406-419 that does
-                      // not depend on the node (depth, pmin, the entropy thresholds against the 0 a single frequency gives) holds;
-                      // bit 3 (one sample): a tile's planes form a 64-byte line {plane[4], candidate bits, candidates | pairs << 32, -, -}
-    u32 cstride;      // packed column: distance, in words, between the entries of consecutive nodes (1, or the number of local samples
-                      // when the level is node-major, see Xchg::nm)
-    u32 w16;          // this level's column: 0 = frequencies as P plus a flag byte; 1 = 16-bit frequencies plus a flag byte (every
-                      // frequency of the level is below 65535); 2 = ONE 16-bit word per node, frequency in bits 0-8 and the flags
-                      // in bits 9-15 (every frequency below 512: all but the top levels of a prefix)
-    SbArgs sb;        // superblock bases of this sample's index
-    u32 cost[4];      // BitRank::rank calls per LF on A,C,G,T in the reference
-    u32 access_pack;  // BitRank::rank calls of getL by 3-bit code, four bits each (a table in the argument block would be a load)
-    u64 costsum_lo, costsum_hi;  // sum of cost[c] over the bases of a 4-bit set, six bits per set: sets 0-9, sets 10-15
-    // A launch queued before the host knows the level (single sample): width and frequency class of the level come from two device
-    // words the previous level's publish kernel wrote; the launch does nothing when the class is not the one the host assumed
-    // (formats are launch-time choices) or the level does not fit -- the host then sees the same words and launches again.
-    const u32* dyn;    // null: F, nbp and the formats above are final
-    u32 dyn_expect, dyn_mask, fcap;
-#ifdef DSM_CLOCK_PROBE
-    u32 probe_slot;    // counter shard that collects this launch's wave times
-    unsigned long long* probe_buf;   // per wave of ONE chosen launch: start, end, hardware ids
-#endif
-};
-
-__device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
-    return (u32)((set < 10 ? a.costsum_lo >> (6 * set) : a.costsum_hi >> (6 * (set - 10))) & 63u);
-}
-// the set bits of a 4-bit mask in increasing order, two bits each (masks 0-7 in LO, 8-15 in HI, eight bits per mask)
-__device__ __forceinline__ u32 bit_list(u32 m) {
-    return (u32)(((m & 8u) ? 0xe439380e340d0c03ull : 0x2409080204010000ull) >> (8 * (m & 7u))) & 0xFFu;
-}
-
-template <typename P> struct Vec4;
-template <> struct Vec4<u32> { typedef uint4 type; };
-template <> struct Vec4<u64> { typedef ulonglong4 type; };
-
-// The LF-step kernel.  A wave owns tiles of 64 consecutive nodes of the (colex-ordered) union level and walks them with a
-// grid stride; the waves of a launch are all resident, so the launch sweeps the level -- and with it the sample's records
-// and the index -- front to back.  While a tile is being ranked, the record heads of the wave's next tile and the handles
-// of the one after are already on their way (two-stage software pipeline), so a tile waits for one memory round trip --
-// its index blocks -- instead of three dependent ones.  Waves never synchronise with each other: a wave's children with
-// symbol c go to the 64 handles  c * seg + 64 * tile ..  of the next record buffer, ranked by ballot.
-// splane receives, per tile, the four bit planes "this sample keeps child c of node j" (the advance kernel derives the
-// children's record handles from them); cnt (single sample only: the union trie is the sample's trie) accumulates the child
-// counts per symbol and 256-node tile for the scan.
-constexpr u32 CREC_WORDS(size_t psize) { return psize == 4 ? 1u : 2u; }  // uint4 per compact record
-
-template <typename P, bool INC>
-struct RecHead;
-template <typename P>
-struct RecHead<P, false> {   // what a lane needs of its record before anything can be ranked (wide format: decoded fields)
-    P sp, ep, e0min, e0max, e1min, e1max;
-    u32 flags;     // bits 0-3: mask of the non-empty left-extension intervals, bit 8: the node is present in this sample
-    u32 r;         // the record's handle (the few nodes with more than two intervals read the others through it)
-};
-template <typename P>
-struct RecHead<P, true> {    // compact format: the raw words, decoded when the tile is worked on
-    uint4 w[sizeof(P) == 4 ? 1 : 2];
-    u32 r;         // handle, DEAD for an absent node
-};
-// Every load of the pipeline is unconditional (absent nodes read record 0 and discard it; the first two interval slots are
-// read whether or not they are in use): a load behind a branch makes the compiler wait for ALL outstanding loads at the join --
-// the prefetches would stop being prefetches -- and one node in ten has two intervals, i.e. nearly every wave has such a lane.
-template <typename P>
-__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, false>& h) {
-    const bool live = r != DEAD;
-    const u32 rr = live ? r : 0u;
-    const P sp = rec[rr], ep = rec[cap + rr];
-    h.e0min = rec[2 * cap + rr]; h.e0max = rec[3 * cap + rr];
-    h.e1min = rec[4 * cap + rr]; h.e1max = rec[5 * cap + rr];
-    const u32 m = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * cap)[rr];
-    h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0;
-    h.flags = live ? (m | 0x100u) : 0u;
-    h.r = rr;
-}
-template <typename P>
-__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, true>& h) {
-    const uint4* c = reinterpret_cast<const uint4*>(rec) + (size_t)(r != DEAD ? r : 0u) * CREC_WORDS(sizeof(P));
-    h.w[0] = c[0];
-    if (sizeof(P) == 8) h.w[sizeof(P) == 4 ? 0 : 1] = c[sizeof(P) == 4 ? 0 : 1];
-    h.r = r;
-}
-// decoded view of a head
-template <typename P>
-struct NodeIn {
-    P sp, ep, e0min, e0max, e1min, e1max;
-    u32 emask, r;
-    bool live;
-};
-template <typename P>
-__device__ __forceinline__ void decode_head(const RecHead<P, false>& h, NodeIn<P>& n) {
-    n.sp = h.sp; n.ep = h.ep; n.e0min = h.e0min; n.e0max = h.e0max; n.e1min = h.e1min; n.e1max = h.e1max;
-    n.emask = h.flags & 15u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
-}
-__device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<u32>& n) {
-    const uint4 v = h.w[0];
-    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
-    const u32 sp = v.x;
-    n.sp = n.live ? sp : 1u;
-    n.ep = n.live ? sp + (v.y & 0xFFFFu) : 0u;
-    n.e0min = sp + (v.y >> 16); n.e0max = sp + (v.z & 0xFFFFu);
-    n.e1min = sp + (v.z >> 16); n.e1max = sp + (v.w & 0xFFFFu);
-    n.emask = n.live ? (v.w >> 16) & 15u : 0u;
-}
-__device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<u64>& n) {
-    const uint4 v = h.w[0], x = h.w[1];
-    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
-    const u64 sp = ((u64)v.y << 32) | v.x;
-    n.sp = n.live ? sp : 1ull;
-    n.ep = n.live ? sp + (v.z & 0xFFFFu) : 0ull;
-    n.e0min = sp + (v.z >> 16); n.e0max = sp + (v.w & 0xFFFFu);
-    n.e1min = sp + (v.w >> 16); n.e1max = sp + (x.x & 0xFFFFu);
-    n.emask = n.live ? (x.x >> 16) & 15u : 0u;
-}
-// A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions (slots 2, 3 went to the wide fields already)
-template <typename P, bool OUTC>
-__device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32 q, P nsp, P nep, P l0, P h0, P l1, P h1, u32 cn, u32 cm) {
-    if (OUTC) {
-        uint4* c = reinterpret_cast<uint4*>(out) + (size_t)q * CREC_WORDS(sizeof(P));
-        const u32 len = (u32)(nep - nsp), a0 = cn > 0 ? (u32)(l0 - nsp) : 0u, b0 = cn > 0 ? (u32)(h0 - nsp) : 0u,
-                  a1 = cn > 1 ? (u32)(l1 - nsp) : 0u, b1 = cn > 1 ? (u32)(h1 - nsp) : 0u;
-        if (sizeof(P) == 4) {
-            c[0] = make_uint4((u32)nsp, len | (a0 << 16), b0 | (a1 << 16), b1 | (cm << 16));
-        } else {
-            c[0] = make_uint4((u32)nsp, (u32)((u64)nsp >> 32), len | (a0 << 16), b0 | (a1 << 16));
-            c[sizeof(P) == 4 ? 0 : 1] = make_uint4(b1 | (cm << 16), 0u, 0u, 0u);
-        }
-    } else {
-        out[q] = nsp;
-        out[cap + q] = nep;
-        if (cn > 0) { out[2 * cap + q] = l0; out[3 * cap + q] = h0; }
-        if (cn > 1) { out[4 * cap + q] = l1; out[5 * cap + q] = h1; }
-        reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[q] = (u8)cm;
-    }
-}
-
-struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
-    // (k <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
-    u32 kne = 0, ll = 0, lf = 0, rank = 0;
-    u32 rbytes = 0;     // bytes of records read and written
-    u32 wide = 0;       // bit 0: some surviving child has a frequency of 512 or more, bit 1: of 65535 or more (the next level's column format)
-};
-
-// One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
-// whose handles are in rn (requested one tile ago); rn then receives the handles of the tile after that.
-// SELF (several samples, no handle table): rp is the level's slot array (4 * parent + base per node, shared by all samples) and a
-// node's handle follows from the planes the sample wrote at the parent level (pplane): child c of the parent at round T, lane j has
-// the handle c * seg + 64 * T + (set bits of plane[T][c] below j), and no handle when the bit is clear.  The pipeline is one stage
-// deeper: slots of the tile three ahead, plane words of the tile two ahead, heads of the next tile.
-struct SelfState {
-    u32 s1 = DEAD, s2 = DEAD;  // slots of the lane's nodes one and two tiles ahead
-    u64 pn = 0;                // plane word for s1
-};
-__device__ __forceinline__ u32 self_handle(u32 slot, u64 plane, u32 seg) {
-    const u32 j = (slot >> 2) & 63u;
-    const bool has = slot != DEAD && ((plane >> j) & 1ull);
-    return has ? (slot & 3u) * seg + ((slot >> 8) << 6) + (u32)__popcll(plane & ((1ull << j) - 1)) : DEAD;
-}
-__device__ __forceinline__ size_t self_plane_index(u32 slot) { return slot != DEAD ? (size_t)(slot >> 8) * 4 + (slot & 3u) : (size_t)0; }
-
-template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF = false>
-__device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, uint4* wl, const u32* __restrict__ rp, const P* __restrict__ rec,
-                                            P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
-                                            u8* __restrict__ pl, const ExpandArgs& a, const u32 t, const u32 nwaves, const u32 ntile,
-                                            const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
-                                            const u64* __restrict__ pplane = nullptr, SelfState* ss = nullptr, const u32* __restrict__ keeptab = nullptr) {
-    const int lane = threadIdx.x & 63;
-    const u64 lt = (1ull << lane) - 1;
-    const size_t cap = a.cap;
-    const u32 i = t * 64 + lane;
-    NodeIn<P> nd;
-    decode_head(hc, nd);
-    const bool live = nd.live;
-    const P sp = nd.sp, ep = nd.ep;
-    const u32 emask = nd.emask;
-    const u32 ne = __popc(emask);
-    u32 keepw = ~0u;  // the word of the keep table that holds this node's frequency (requested here, used at the candidate ballot)
-    const u64 freq1 = (u64)ep - (u64)sp + 1;
-    if (!SELF) keepw = keeptab[(freq1 < KEEP_FREQS ? (u32)freq1 : 0u) >> 5];
-    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;  // blocks of the two interval ends
-    u32 n_lf = 0, n_rank = 0, lines = 0;
-    P Rsp[4], Rep[4];
-    u32 present = 0;  // bit c: child c is emitted
-    u32 idx0, idx1;   // numbers of this lane's two blocks among the tile's distinct blocks
-    u32 rb_out = 0;   // bytes of child records this lane writes
-    {
-        // ---- the distinct blocks of the tile (see the staging note above) ----
-        u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
-        u32 pm = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane; running maximum over the lanes below = the last block listed
-        if (!__all(live)) {  // absent nodes in between (several samples, or the last tile): the maximum is carried across them
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
-        }
-        u32 prev = __shfl_up(pm, 1, 64);  // (every lane present: the blocks increase along the lanes, the lane below holds the maximum)
-        if (lane == 0) prev = 0;
-        const bool f0 = live && (u32)b0 + 1u > prev, f1 = live && b1 != b0;
-        const u64 m0 = __ballot(f0), m1 = __ballot(f1);
-        const u32 D = (u32)__popcll(m0) + (u32)__popcll(m1);
-        const u32 before = bits_below_lane(m0) + bits_below_lane(m1);
-        idx0 = f0 ? before : (before ? before - 1u : 0u);
-        idx1 = f1 ? idx0 + 1u : idx0;
-        if (!live) { idx0 = 0; idx1 = 0; }
-        lines = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
-        if (f0) list[idx0] = (u32)b0;
-        if (f1) list[idx1] = (u32)b1;
-        if (D == 0 && lane == 0) list[0] = 0;
-        const u32 Dm1 = D ? D - 1u : 0u;
-        const u32 g = (u32)lane >> 2, qq = (u32)lane & 3u;
-        // four lanes per block, sixteen blocks per instruction; lanes beyond the last block repeat it
-        uint4 v0, v1, v2, v3;
-        {
-            const u32 d0 = g < Dm1 ? g : Dm1, d1 = g + 16 < Dm1 ? g + 16 : Dm1, d2 = g + 32 < Dm1 ? g + 32 : Dm1, d3 = g + 48 < Dm1 ? g + 48 : Dm1;
-            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
-            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
-            v0 = base[(size_t)bb0 * 4 + qq]; v1 = base[(size_t)bb1 * 4 + qq]; v2 = base[(size_t)bb2 * 4 + qq]; v3 = base[(size_t)bb3 * 4 + qq];
-        }
-        if (D > 64) {  // (wave-uniform) the rarer second half
-            const u32 d0 = g + 64 < Dm1 ? g + 64 : Dm1, d1 = g + 80 < Dm1 ? g + 80 : Dm1, d2 = g + 96 < Dm1 ? g + 96 : Dm1, d3 = g + 112 < Dm1 ? g + 112 : Dm1;
-            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
-            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
-            const uint4 w0 = base[(size_t)bb0 * 4 + qq], w1 = base[(size_t)bb1 * 4 + qq], w2 = base[(size_t)bb2 * 4 + qq], w3 = base[(size_t)bb3 * 4 + qq];
-            wl[256 + lane] = w0; wl[320 + lane] = w1; wl[384 + lane] = w2; wl[448 + lane] = w3;
-        }
-        // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
-        // the blocks leaves them in flight) ----
-        if (SELF) {
-            load_head<P>(rec, cap, self_handle(ss->s1, ss->pn, a.seg), hn);
-            ss->pn = pplane[self_plane_index(ss->s2)];
-            ss->s1 = ss->s2;
-            const u32 t3 = t + 3 * nwaves;
-            const u32 i3 = t3 * 64 + lane;
-            const bool in3 = t3 < ntile && i3 < a.F;
-            const u32 v = rp[in3 ? i3 : 0u];
-            ss->s2 = in3 ? v : DEAD;
-        } else {
-            load_head<P>(rec, cap, rn, hn);
-            const u32 t2 = t + 2 * nwaves;
-            const u32 i2 = t2 * 64 + lane;
-            const bool in2 = t2 < ntile && i2 < a.F;
-            const u32 v = rp[in2 ? i2 : 0u];
-            rn = in2 ? v : DEAD;
-        }
-        wl[lane] = v0; wl[64 + lane] = v1; wl[128 + lane] = v2; wl[192 + lane] = v3;
-        asm volatile("" ::: "memory");  // the blocks are read back from LDS (other lanes' words among them)
-        // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty.
-        Blk16 r0;
-        staged_blk(wl, idx0, r0);
-        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)sp, Rsp);  // LF(c, sp-1)
-        const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
-        staged_blk(wl, idx1, r0);
-        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
-        const bool single = (a.symbol_phase & 1u) && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
-        u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if ((a.allowed >> c) & 1u) {
-                const P nsp = Rsp[c], nep = Rep[c] - 1;
-                if (nsp <= nep) {
-                    nonempty |= 1u << c;
-                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
-                        present |= 1u << c;
-                        if ((u64)(nep - nsp) + 1 >= PACK_FMAX) acc.wide |= (u64)(nep - nsp) + 1 >= 65535 ? 3u : 1u;
-                    }
-                }
-            }
-        }
-        // What the reference would have spent on this node: two LF per attempted base (Query::pushChar, Query.h:37-45) and two per
-        // left-extension interval for every base whose interval is non-empty; BitRank::rank calls = LF calls weighted by the
-        // base's code length (a.costsum: the sums per set of bases, six bits each).
-        n_lf = 2 * (u32)__popc(a.allowed) + 2 * ne * (u32)__popc(nonempty);
-        n_rank = 2 * costsum(a, a.allowed) + 2 * ne * costsum(a, nonempty);
-        if (__any(single)) {  // nodes of frequency 1 follow one branch by getL instead (only reachable with fmin = 1)
-            if (single) {
-                const bool go = a.allowed && ((nonempty >> lcode) & 1u) && lcode < 4;
-                n_lf = go ? 2 * ne + 2 : 0u;
-                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * DSM_PICK(a.cost, lcode) : 0u);
-            }
-        }
-        if (!live) { n_lf = 0; n_rank = 0; present = 0; }
-    }
-    // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
-    const u32 k = __popc(present);
-    u64 bal[4];
-    u32 qa[4];  // handle of this lane's child with symbol c
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        bal[c] = __ballot((present >> c) & 1u);
-        qa[c] = (u32)c * a.seg + t * 64 + (u32)__popcll(bal[c] & lt);
-    }
-    if (lane < 4) {
-        const u64 b = DSM_PICK(bal, lane);
-        if (!(a.symbol_phase & 8u)) splane[(size_t)t * 4 + lane] = b;
-        const u32 nb = (u32)__popcll(b);
-        if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
-    }
-    // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
-    bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
-    if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
-        if (ne > 2) {
-#pragma unroll
-            for (int e = 2; e < 4; ++e)
-                if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * cap + nd.r] == sp && rec[(size_t)(3 + 2 * e) * cap + nd.r] == ep) matches = true;
-        }
-    }
-    const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
-    if (a.symbol_phase & 8u) {  // one sample: planes and the level's candidates in one line per tile (the advance sweep reads it)
-        // metaserver.cpp:406-419 for a node with one reader: not a single child (416-417), no single left char (383-387, 418)
-        const bool ekeep = SELF || freq1 >= KEEP_FREQS || ((keepw >> ((u32)freq1 & 31u)) & 1u);  // the exact entropy verdict for this frequency
-        const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u) && ekeep);
-        if (lane < 6) {
-            const u64 nc = (u64)__popcll(cb);
-            const u64 word = lane < 4 ? DSM_PICK(bal, lane) : (lane == 4 ? cb : (nc | (nc << 32)));
-            splane[(size_t)t * 8 + lane] = word;
-        }
-    }
-    // ---- child records.  A lane's work is the list of its (child, left-extension interval) pairs, child-major: most lanes have
-    // one pair, one in ten has two, so a wave runs about two rounds instead of (most children) x (most intervals).  Per pair: LF
-    // with the child's base at both ends of the parent's interval (EnumerateQuery.cpp:44-55) -- an end that coincides with sp or
-    // ep + 1 is the child's own end -- and the child keeps the interval if it stays non-empty, compacted into its first slots.
-    // The ends lie inside [sp, ep + 1], i.e. in one of the two parked blocks unless the interval spans more than two blocks.
-    {
-        const u32 ne1 = ne ? ne : 1u;
-        const u32 npair = k * ne1;
-        const u32 cjpack = bit_list(present), kkpack = bit_list(emask);  // two bits per slot: bases of the children / of the intervals, in order
-        u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
-        P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
-        P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
-        rb_out = 0;
-#pragma nounroll
-        for (u32 p = 0; __any(p < npair); ++p) {
-            const bool act = p < npair;
-            const u32 j = ne1 == 1 ? p : (ne1 == 2 ? p >> 1 : (ne1 == 4 ? p >> 2 : (p * 11u) >> 5));  // p / ne1 for p < 16
-            const u32 e = p - j * ne1;
-            const u32 c = (cjpack >> (2 * j)) & 3u, kk = (kkpack >> (2 * e)) & 3u;
-            const u32 q = DSM_PICK(qa, c);
-            const P nsp = DSM_PICK(Rsp, c), nep1 = DSM_PICK(Rep, c);  // the child's interval is [nsp, nep1 - 1]
-            if (e == 0) { cn = 0; cm = 0; }
-            const bool hasext = act && ne > 0;
-            P xmin = e == 0 ? nd.e0min : nd.e1min, xmax = e == 0 ? nd.e0max : nd.e1max;
-            if (__any(hasext && e > 1)) {
-                if (hasext && e > 1) {
-                    xmin = rec[(size_t)(2 + 2 * e) * cap + nd.r];
-                    xmax = rec[(size_t)(3 + 2 * e) * cap + nd.r];
-                }
-            }
-            const u64 xl = hasext ? (u64)xmin : (u64)sp, xh = hasext ? (u64)xmax + 1 : (u64)ep + 1;
-            P l = nsp, h = nep1;
-            bool needl = xl != (u64)sp;
-            const bool needh = xh != (u64)ep + 1;
-            if (e > 0 && xl == prevx) { l = prevh; needl = false; }  // adjacent intervals share an end: the rank is the previous pair's
-            if (__any(needl)) {
-                if (needl) {
-                    const u64 bl = xl >> BLK_SHIFT;
-                    if (bl == b0 || bl == b1) l = rank_staged<P, ONESB>(a.sb, sbl, wl, bl != b0 ? idx1 : idx0, xl, c);
-                    else { l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c); ++lines; }
-                }
-            }
-            if (__any(needh)) {
-                if (needh) {
-                    const u64 bh = xh >> BLK_SHIFT;
-                    if (bh == b0 || bh == b1) h = rank_staged<P, ONESB>(a.sb, sbl, wl, bh != b0 ? idx1 : idx0, xh, c);
-                    else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
-                }
-            }
-            prevx = (P)xh; prevh = h;
-            if (hasext && l <= h - 1) {
-                if (cn == 0) { kl0 = l; kh0 = h - 1; }
-                else if (cn == 1) { kl1 = l; kh1 = h - 1; }
-                else { out[(size_t)(2 + 2 * cn) * cap + q] = l; out[(size_t)(3 + 2 * cn) * cap + q] = h - 1; }  // slots 2, 3: wide fields
-                ++cn;
-                cm |= 1u << kk;
-            }
-            if (act && e == ne1 - 1) {
-                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
-                rb_out += (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1) + (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P)) +
-                          (cn > 2 ? (cn - 2) * 2u * (u32)sizeof(P) : 0u);
-            }
-        }
-    }
-    if (i < a.F) {
-        // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
-        if (a.w16 == 2) {
-            reinterpret_cast<u16*>(valf)[(size_t)i * a.cstride] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
-        } else {
-            if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
-            else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
-            pl[i] = (u8)(present | (mycode << 4));
-        }
-    }
-    acc.kne += (a.symbol_phase & 2u) ? k : 0u; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
-    // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
-    // when in use) and its children's (compact word each, or their fields; rb_out collected by the rounds)
-    acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
-}
-
-// One sample's LF-step sweep over a level: the body of expand_kernel (one sample per launch) and of expand_batch_kernel.
-template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF = false>
-__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, const u32* __restrict__ rp, const P* __restrict__ rec,
-                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
-                                             u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
-                                             unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane = nullptr) {
-    uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
-    if (!ONESB) {
-        const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
-        for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63;
-    const u32 nwaves = gridDim.x * 4;
-    const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    const u32 t0 = gw;
-    const u32 ntile = (a.F + 63) >> 6;
-    const u32* keeptab = reinterpret_cast<const u32*>(counters + (size_t)COUNTER_SHARDS * 8);  // (see KEEP_FREQS)
-    ExpandAcc acc;
-#ifdef DSM_CLOCK_PROBE
-    const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
-#endif
-    {
-        // prologue of the pipeline: heads of the wave's first tile, handles of its second
-        u32 rn = DEAD;
-        u32 r0 = DEAD;
-        const u32 i0 = t0 * 64 + lane, i1 = (t0 + nwaves) * 64 + lane;
-        if (t0 < ntile && i0 < a.F) r0 = rp[i0];
-        if (t0 + nwaves < ntile && i1 < a.F) rn = rp[i1];
-        SelfState ss;
-        if (SELF) {  // r0, rn hold slots here: handles of the first tile now, the deeper stages primed
-            const u32 i2 = (t0 + 2 * nwaves) * 64 + lane;
-            ss.s1 = rn;
-            if (t0 + 2 * nwaves < ntile && i2 < a.F) ss.s2 = rp[i2];
-            const u64 p0 = pplane[self_plane_index(r0)];
-            ss.pn = pplane[self_plane_index(ss.s1)];
-            r0 = self_handle(r0, p0, a.seg);
-        }
-        RecHead<P, INC> hA, hB;
-        load_head<P>(rec, a.cap, r0, hA);
-        // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied
-        for (u32 t = t0; t < ntile; t += 2 * nwaves) {
-            expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t, nwaves, ntile, hA, hB, rn, acc, pplane, &ss, keeptab);
-            if (t + nwaves < ntile)
-                expand_tile<P, ONESB, INC, OUTC, SELF>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t + nwaves, nwaves, ntile, hB, hA, rn, acc, pplane, &ss, keeptab);
-        }
-    }
-#ifdef DSM_CLOCK_PROBE
-    if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
-        atomicAdd((unsigned long long*)&counters[6], (unsigned long long)(__builtin_readcyclecounter() - probe_c0));
-        atomicAdd((unsigned long long*)&counters[7], (unsigned long long)(wall_clock64() - probe_r0));
-    }
-    if (lane == 0 && t0 < ntile) {  // every wave with tiles: its start and end (100 MHz ticks): earliest, latest and sum of both, per launch (three shards)
-        const unsigned long long e1 = (unsigned long long)wall_clock64(), s1 = (unsigned long long)probe_r0;
-        unsigned long long* q = (unsigned long long*)&counters[(size_t)a.probe_slot * 8];
-        atomicMax(q + 6, ~s1); atomicMax(q + 7, s1);
-        atomicMax(q + 8 + 6, ~e1); atomicMax(q + 8 + 7, e1);
-        atomicAdd(q + 16 + 6, s1 & 0xFFFFFFFFull); atomicAdd(q + 16 + 7, e1 & 0xFFFFFFFFull);
-        if (a.probe_buf && gw < 8192) {
-            const u32 hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-            a.probe_buf[(size_t)gw * 3] = s1; a.probe_buf[(size_t)gw * 3 + 1] = e1; a.probe_buf[(size_t)gw * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
-        }
-    }
-#endif
-    // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
-    if (__any(acc.wide != 0) && lane == 0) atomicMax(childmax, __any((acc.wide & 2u) != 0) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
-    {
-        u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
-#pragma unroll
-        for (int q = 0; q < NCOUNTERS; ++q) v[q] = wave_sum_u64(v[q]);
-        if (lane < NCOUNTERS) {
-            u64 mine = v[0];
-#pragma unroll
-            for (int q = 1; q < NCOUNTERS; ++q) mine = lane == q ? v[q] : mine;
-            if (mine) atomicAdd((unsigned long long*)&counters[(size_t)(gw & (COUNTER_SHARDS - 1)) * 8 + lane], (unsigned long long)mine);
-        }
-    }
-}
-
-// (32-bit positions fit four waves per SIMD without spilling when the allocator is told to aim for it; 64-bit positions take three)
-template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) == 4 ? 4 : 3))) void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out,
-                                                     u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
-                                                     u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters,
-                                                     unsigned long long* __restrict__ childmax) {
-    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
-    __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
-    if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
-        const u32 F = a.dyn[0], cls = a.dyn[1];
-        if ((cls & a.dyn_mask) != a.dyn_expect || F > a.fcap || F == 0) return;
-        a.F = F;
-        a.nbp = (F + TILE - 1) / TILE;
-        if (a.w16 != 2) pl = reinterpret_cast<u8*>(valf) + (size_t)F * (a.w16 ? 2u : (u32)sizeof(P));  // one sample: the flag bytes follow its frequencies
-        if (a.nbp <= 1) cnt = nullptr;
-    }
-    expand_sweep<P, ONESB, INC, OUTC>(ix, sbl, parked, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
-}
-
-// Several samples of one process in one launch: blockIdx.y picks the sample (its index, record buffers, columns and code costs come
-// from the batch block), so a level's launches are not eight short ones with eight tails but one wide one.
-struct ExpandSample {
-    DevIndex ix;
-    const u32* rp;
-    const void* rec;
-    void* out;
-    u64* splane;
-    const u64* pplane;  // the planes this sample wrote at the parent level (handles are derived from them, see expand_tile)
-    void* valf;
-    u8* pl;
-    SbArgs sb;
-    u32 cost[4];
-    u32 access_pack, pad;
-    u64 costsum_lo, costsum_hi;
-};
-constexpr int BATCH_MAX = 8;
-struct ExpandBatch {
-    ExpandSample s[BATCH_MAX];
-};
-template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(P) == 4 ? 4 : 3))) void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters,
-                                                                                                        unsigned long long* __restrict__ childmax) {
-    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
-    __shared__ uint4 parked[4 * WAVE_LDS_WORDS];
-    const ExpandSample& S = b.s[blockIdx.y];
-    a.sb = S.sb;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a.cost[c] = S.cost[c];
-    a.access_pack = S.access_pack;
-    a.costsum_lo = S.costsum_lo;
-    a.costsum_hi = S.costsum_hi;
-    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
-}
 
 constexpr u32 BC_OK = 0x4f4b4f4bu, BC_CAPACITY = 0x46554c4cu;  // first word of the owner's broadcast: go on / split this prefix
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
@@ -2544,7 +1889,7 @@ class Engine {
     u64 bpr_cap = 0;
     u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced -> scanned offsets
     u32* cntraw = nullptr;                     // single sample: the counts as the expand kernel accumulates them (kept zero between levels)
-    u32 expand_blocks = 1024;                  // resident blocks of the LF-step kernel (its waves walk the level with a grid stride)
+    LfGeometry lfgeo{256, 16};                 // resident workgroups of the LF-step kernel and their waves (expand.hip)
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8* samechild = nullptr;
@@ -2552,10 +1897,6 @@ class Engine {
     u16* order16[2] = {nullptr, nullptr};  // d > 13
     u64 *cand_wsum = nullptr, *cand_wscan = nullptr, *scan_tmp64 = nullptr;  // per wave of 64 nodes: candidates | pairs << 32, and their scan
     u64* d_counters = nullptr;
-#ifdef DSM_CLOCK_PROBE
-    unsigned long long* d_probe = nullptr;
-    u32 probe_F = 0;
-#endif
     u32* d_totals = nullptr;
     u64* d_totals64 = nullptr;
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, [8..8+MAX_LOCAL) record allocations, [300..] u64 totals
@@ -2743,14 +2084,7 @@ class Engine {
             if (int rc = dalloc(cntraw, 4 * ntile + 8)) return rc;
             DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
         }
-        {   // all waves of an LF-step launch are resident: blocks = CUs x blocks per CU at the kernel's register footprint
-            int cus = 0, per = 0;
-            DSM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            DSM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (expand_kernel<P, true, true, true>), 256, 0));
-            if (const char* e = getenv("DSM_EXPAND_BLOCKS_PER_CU")) per = atoi(e);
-            if (per < 1) per = 1;
-            expand_blocks = (u32)(cus > 0 ? cus : 256) * (u32)per;
-        }
+        if (int rc = lf_step_geometry(sizeof(P) == 8, device, &lfgeo)) return rc;  // (all waves of an LF-step launch are resident)
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
@@ -3001,12 +2335,7 @@ class Engine {
                 const bool ent_ok = !(prm.emax > 0 && (0.0 < prm.emin - ENT_MARGIN || 0.0 > prm.emax + ENT_MARGIN));
                 if (emit_level && depth >= prm.mindepth && prm.pmin <= 1 && ent_ok) ea.symbol_phase |= 4u;
             }
-#ifdef DSM_CLOCK_PROBE
-            ea.probe_slot = 1u + 3u * ((u32)(nev / 2) % (u32)((COUNTER_SHARDS - 4) / 3));
-            if (!d_probe) { DSM_HIP(hipMalloc((void**)&d_probe, 8192 * 3 * sizeof(u64))); }
-            ea.probe_buf = (nev / 2 == 50) ? d_probe : nullptr;
-            if (ea.probe_buf) { DSM_HIP(hipMemsetAsync(d_probe, 0, 8192 * 3 * sizeof(u64), st)); probe_F = F ? F : (u32)(Fmax / 4); }
-#endif
+            ea.probe_slot = 1u + 3u * ((u32)(nev / 2) % (u32)((COUNTER_SHARDS - 4) / 3));  // (read by DSM_CLOCK_PROBE builds of expand.hip only)
             hipEvent_t ea0 = pool_event(nev++), ea1 = pool_event(nev++);
             if (!ea0 || !ea1) return fail(DSM_E_HIP, "hipEventCreate failed");
             std::unique_lock<std::mutex> chain_lock(g_expand_chain.mu);
@@ -3025,7 +2354,6 @@ class Engine {
                     DSM_HIP(hipMemsetAsync(cl, 0, (size_t)F, st));
                 }
             }
-            const u32 need = (F + TILE - 1) / TILE;
             ExpandBatch eb;
             int nb = 0;
             bool all_one_sb = true;
@@ -3061,24 +2389,14 @@ class Engine {
                 ++nb;
                 stats.expand_slots += F;
                 stats.expand_column_bytes += (u64)F * colb;
-                const bool oc = w16;
+                LfConfig lc;
+                lc.wide_pos = sizeof(P) == 8; lc.fmt_in = fmt_in; lc.fmt_out = w16;
                 // record formats: this level's records are compact iff its parent level was narrow (fmt_in), the children's iff this one is
-#define DSM_FORMATS(LAUNCH, SB)                                                               \
-    do {                                                                                      \
-        if (fmt_in) { if (oc) LAUNCH(SB, true, true); else LAUNCH(SB, true, false); }         \
-        else { if (oc) LAUNCH(SB, false, true); else LAUNCH(SB, false, false); }              \
-    } while (0)
                 if (self_mode) {  // several samples: one launch for up to BATCH_MAX of this process's
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;
-                    // (measured with eight samples: 2 x resident -> 1255, 4 x -> 1219, 8 x -> 1189, 16 x -> 1184, 32 x -> 1198 ms per pass: the samples'
-                    // sweeps finish unevenly, shorter wave strides even them out)
                     static const u32 grid_factor = getenv("DSM_BATCH_GRID_FACTOR") ? (u32)atoi(getenv("DSM_BATCH_GRID_FACTOR")) : 8u;
-                    u32 gx = (grid_factor ? grid_factor : 8u) * expand_blocks / (u32)nb;
-                    if (gx < 1) gx = 1;
-                    const dim3 bg(need < gx ? need : gx, (u32)nb);
-#define DSM_LAUNCH_BATCH(SB, IC, OC) hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), bg, dim3(256), 0, st, eb, ea, d_counters, d_childmax)
-                    if (all_one_sb) DSM_FORMATS(DSM_LAUNCH_BATCH, true); else DSM_FORMATS(DSM_LAUNCH_BATCH, false);
-#undef DSM_LAUNCH_BATCH
+                    lc.one_sb = all_one_sb;
+                    lf_step_launch_batch(lc, lfgeo, grid_factor ? grid_factor : 8u, nb, st, eb, ea, d_counters, d_childmax);
                     nb = 0;
                     ++stats.expand_launches;
                     continue;
@@ -3087,18 +2405,12 @@ class Engine {
                 ea.sb = es.sb;
                 for (int c = 0; c < 4; ++c) ea.cost[c] = es.cost[c];
                 ea.access_pack = es.access_pack; ea.costsum_lo = es.costsum_lo; ea.costsum_hi = es.costsum_hi;
-                const bool one_sb = (m.n >> SB_SHIFT) == 0;
-                P* cf = reinterpret_cast<P*>(es.valf);
-                u8* cl = es.pl;
-                const u64 dneed = Fmax == ~0ull ? (u64)expand_blocks : (Fmax + TILE - 1) / TILE;
-                const dim3 eg(dynamic ? (u32)(dneed < expand_blocks ? (dneed ? dneed : 1) : expand_blocks) : (need < expand_blocks ? need : expand_blocks));
+                lc.one_sb = (m.n >> SB_SHIFT) == 0;
                 u32* ecnt = (d == 1 && (ea.nbp > 1 || dynamic)) ? cntraw : (u32*)nullptr;
-#define DSM_LAUNCH_EXPAND(SB, IC, OC)                                                                                               \
-    hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), eg, dim3(256), 0, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], \
-                       ecnt, cf, cl, ea, d_counters, d_childmax)
-                if (one_sb) DSM_FORMATS(DSM_LAUNCH_EXPAND, true); else DSM_FORMATS(DSM_LAUNCH_EXPAND, false);
-#undef DSM_LAUNCH_EXPAND
-#undef DSM_FORMATS
+                // (a launch queued ahead: Fmax bounds the level -- four children per node of the level before it)
+                const u64 tiles_bound = dynamic ? (Fmax == ~0ull ? ~0ull >> 8 : (Fmax + 63) / 64) : ((u64)F + 63) / 64;
+                lf_step_launch(lc, lfgeo, tiles_bound, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, es.valf, es.pl, ea, d_counters,
+                               d_childmax);
                 ++stats.expand_launches;
             }
             DSM_HIP(hipEventRecord(ea1, st));
@@ -3439,70 +2751,6 @@ class Engine {
             DSM_HIP(hipMemcpy(sh.data(), d_counters, sh.size() * sizeof(u64), hipMemcpyDeviceToHost));
             for (int k = 0; k < COUNTER_SHARDS; ++k)
                 for (int c = 0; c < NCOUNTERS; ++c) hc[c] += sh[(size_t)k * 8 + c];
-#ifdef DSM_CLOCK_PROBE
-            if (sh[7]) {
-                double dur = 0, ramp = 0, tail = 0, meanbusy = 0;
-                int nl = 0;
-                const double W = (double)expand_blocks * 4;
-                for (int k = 1; k + 2 < COUNTER_SHARDS; k += 3) {
-                    const u64 s0 = ~sh[(size_t)k * 8 + 6], s9 = sh[(size_t)k * 8 + 7], e0 = ~sh[(size_t)(k + 1) * 8 + 6], e9 = sh[(size_t)(k + 1) * 8 + 7];
-                    if (!s9 || e9 - s0 < 5000) continue;   // launches of 50 us or more
-                    const double ms = (double)sh[(size_t)(k + 2) * 8 + 6] / W, me = (double)sh[(size_t)(k + 2) * 8 + 7] / W;  // (low 32 bits of the ticks, summed)
-                    dur += (double)(e9 - s0); ramp += (double)(s9 - s0); tail += (double)(e9 - e0); meanbusy += me - ms; ++nl;
-                }
-                if (d_probe && probe_F) {
-                    std::vector<u64> pb(8192 * 3);
-                    DSM_HIP(hipMemcpy(pb.data(), d_probe, pb.size() * sizeof(u64), hipMemcpyDeviceToHost));
-                    u64 t0 = ~0ull, t9 = 0;
-                    for (int w = 0; w < 8192; ++w) if (pb[w * 3 + 1]) { t0 = pb[w * 3] < t0 ? pb[w * 3] : t0; t9 = pb[w * 3 + 1] > t9 ? pb[w * 3 + 1] : t9; }
-                    double byx[16] = {0}, byse[8] = {0}; int nx[16] = {0}, nse[8] = {0};
-                    double bysimd[4] = {0}; int nsimd[4] = {0}; int nmis = 0;
-                    std::map<u32, std::pair<double, int>> bycu;
-                    for (int w = 0; w < 8192; ++w) {
-                        if (!pb[w * 3 + 1]) continue;
-                        const double e = (double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0);
-                        const u32 hw = (u32)pb[w * 3 + 2], xcc = (u32)(pb[w * 3 + 2] >> 32) & 15u;
-                        byx[xcc] += e; ++nx[xcc];
-                        if (xcc != (u32)((w >> 2) & 7)) ++nmis;
-                        const u32 se = (hw >> 13) & 7u, cu = (hw >> 8) & 15u, simd = (hw >> 4) & 3u;
-                        byse[se] += e; ++nse[se]; bysimd[simd] += e; ++nsimd[simd];
-                        auto& q = bycu[(xcc << 8) | (se << 4) | cu]; q.first += e; q.second++;
-                    }
-                    {   // spread of the wave ends inside every XCC
-                        std::vector<double> ends[16];
-                        for (int w = 0; w < 8192; ++w) if (pb[w * 3 + 1]) ends[(pb[w * 3 + 2] >> 32) & 15u].push_back((double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0));
-                        fprintf(stderr, "probe launch F=%u: wave ends inside an XCC (min / 10%% / median / 90%% / max):", probe_F);
-                        for (int k = 0; k < 16; ++k) {
-                            if (ends[k].empty()) continue;
-                            std::sort(ends[k].begin(), ends[k].end());
-                            const size_t n = ends[k].size();
-                            fprintf(stderr, " %d: %.2f %.2f %.2f %.2f %.2f;", k, ends[k][0], ends[k][n / 10], ends[k][n / 2], ends[k][n * 9 / 10], ends[k][n - 1]);
-                        }
-                        fprintf(stderr, "\n");
-                    }
-                    {   // by dispatch order: blocks in sixteenths of the grid
-                        double sum[16] = {0}; int n[16] = {0};
-                        const int per = (int)(expand_blocks * 4 / 16);
-                        for (int w = 0; w < 8192 && per; ++w) if (pb[w * 3 + 1]) { const int q = w / per < 16 ? w / per : 15; sum[q] += (double)(pb[w * 3 + 1] - t0) / (double)(t9 - t0); ++n[q]; }
-                        fprintf(stderr, "probe launch F=%u: mean relative end by sixteenth of the grid (dispatch order):", probe_F);
-                        for (int q = 0; q < 16; ++q) if (n[q]) fprintf(stderr, " %.3f", sum[q] / n[q]);
-                        fprintf(stderr, "\n");
-                    }
-                    fprintf(stderr, "probe launch F=%u: %.1f us; mean relative end by XCC:", probe_F, (double)(t9 - t0) * 0.01);
-                    for (int k = 0; k < 16; ++k) if (nx[k]) fprintf(stderr, " %d:%.3f(%d)", k, byx[k] / nx[k], nx[k]);
-                    fprintf(stderr, "; by SE:");
-                    for (int k = 0; k < 8; ++k) if (nse[k]) fprintf(stderr, " %d:%.3f(%d)", k, byse[k] / nse[k], nse[k]);
-                    fprintf(stderr, "; by SIMD:");
-                    for (int k = 0; k < 4; ++k) if (nsimd[k]) fprintf(stderr, " %d:%.3f(%d)", k, bysimd[k] / nsimd[k], nsimd[k]);
-                    double lo = 2, hi = 0; int ncu = 0, minw = 1 << 30, maxw = 0;
-                    for (auto& kv : bycu) { const double m = kv.second.first / kv.second.second; lo = m < lo ? m : lo; hi = m > hi ? m : hi; ++ncu; minw = kv.second.second < minw ? kv.second.second : minw; maxw = kv.second.second > maxw ? kv.second.second : maxw; }
-                    fprintf(stderr, "; %d CUs: mean relative end %.3f .. %.3f, waves per CU %d .. %d; waves whose XCC is not block %% 8: %d\n", ncu, lo, hi, minw, maxw, nmis);
-                    probe_F = 0;
-                }
-                fprintf(stderr, "clock probe: %.1f MHz; %d launches >= 50 us: duration %.2f ms, first-to-last wave start %.2f ms, first-to-last wave end %.2f ms, mean wave busy %.2f ms\n",
-                        (double)sh[6] / (double)sh[7] * 100.0, nl, dur * 1e-5, ramp * 1e-5, tail * 1e-5, meanbusy * 1e-5);
-            }
-#endif
         }
         stats.reported += hc[0];
         stats.lf_steps += hc[1];

@@ -1,0 +1,697 @@
+// expand.hip -- the LF-step kernel (gfx950): one sweep of a sample over a frontier level.
+//
+// The reference walks each sample's suffix trie depth first, one LF call at a time (EnumerateQuery::nextSymbol,
+// EnumerateQuery.cpp:151-238; Query::pushChar, Query.h:37-45; EnumerateQuery::pushChar / leftChar, EnumerateQuery.cpp:39-103).
+// Here one lane takes one frontier node: the four child intervals, the left-extension intervals of every child, the fmin test and
+// the left-char code, fused.  Child records go to the wave's own handles of the next record buffer, the frequency column and the
+// left-char codes to the exchange buffer, the child planes to the advance sweep.  See lfstep.h for the record layout and the order
+// of a level.
+//
+// Work distribution (round 4).  A workgroup is a whole CU: as many waves as fit at the kernel's register footprint (16 with 32-bit
+// positions, 12 with 64-bit ones), and its waves take their tiles of 64 nodes from a counter in LDS instead of a fixed stride.  A SIMD
+// issues from its oldest wave first, so with a fixed share per wave the first wave of every SIMD was done at 0.6 of a launch and the
+// last one ran its tail alone, without anybody to hide its memory waits behind; with the counter the waves of a CU end within a tile
+// of each other.  A CU's tiles are rows of consecutive tiles, G rows apart (G = workgroups of the launch): the launch still sweeps
+// the level -- and with it the sample's records and the index -- front to back.
+#include "lfstep.h"
+
+namespace dsm {
+
+#ifdef DSM_LF_STATIC
+constexpr bool LF_DYNAMIC = false;   // round 3's distribution: 256-thread workgroups, a fixed stride of tiles per wave (kept for A/B runs)
+#else
+constexpr bool LF_DYNAMIC = true;
+#endif
+template <typename P>
+struct LfShape {
+    static constexpr int WAVES_PER_SIMD = sizeof(P) == 4 ? 4 : 3;   // 128 / 168 vector registers
+    static constexpr int WPB = LF_DYNAMIC ? 4 * WAVES_PER_SIMD : 4;  // waves per workgroup
+};
+
+// ---------------------------------------------------------------------------------------------
+// rank on the bit-plane blocks
+// ---------------------------------------------------------------------------------------------
+// occurrences of A,C,G,T among the first `off` symbols of a block with four population counts:
+// |base|, |base & p1| = G+T, |base & p0| = C+T, |base & p1 & p0| = T
+__device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4]) {
+    u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
+    u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+    u64 ba = ma & ~r.p2a, bb = mb & ~r.p2b;
+    u64 h1a = ba & r.p1a, h1b = bb & r.p1b;
+    u32 tot = __popcll(ba) + __popcll(bb);
+    u32 s1 = __popcll(h1a) + __popcll(h1b);
+    u32 s0 = __popcll(ba & r.p0a) + __popcll(bb & r.p0b);
+    u32 s3 = __popcll(h1a & r.p0a) + __popcll(h1b & r.p0b);
+    out[3] = s3; out[2] = s1 - s3; out[1] = s0 - s3; out[0] = tot - s1 - s0 + s3;
+}
+
+// LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
+template <typename P, bool ONESB>
+__device__ __forceinline__ void rank4_blk(const SbArgs& sa, const u64* sbl, const Blk16& r, u64 x, P out[4]) {
+    u32 c4[4];
+    blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (P)((ONESB ? sa.sb0[c] : sbl[(x >> SB_SHIFT) * 4 + c]) + r.cnt[c] + c4[c]);
+}
+
+// LF(c, x-1) for one base chosen per lane (c = 0..3), on the plane words of a block; cntc = the block's count of that base.
+// A plane is taken as it is or inverted, so the base needs no branch.
+template <typename P, bool ONESB>
+__device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a, u64 p0b, u64 p1a, u64 p1b, u64 p2a, u64 p2b, u32 cntc, u64 x, u32 c) {
+    const u32 off = (u32)(x & (BLK_SYMS - 1));
+    const u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
+    const u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
+    const u64 i0 = (c & 1u) ? 0ull : ~0ull, i1 = (c & 2u) ? 0ull : ~0ull;
+    const u64 xa = ma & ~p2a & (p1a ^ i1) & (p0a ^ i0);
+    const u64 xb = mb & ~p2b & (p1b ^ i1) & (p0b ^ i0);
+    const u64 base = ONESB ? DSM_PICK(sa.sb0, c) : sbl[(x >> SB_SHIFT) * 4 + c];
+    return (P)(base + cntc + (u32)(__popcll(xa) + __popcll(xb)));
+}
+
+// The index blocks of a tile are staged in LDS.  The intervals of a tile's nodes are disjoint and increase along the lanes, so
+// the blocks the lanes need (block of sp, block of ep + 1) form a non-decreasing sequence: the distinct ones -- about 0.7 per node
+// in the wide levels, where neighbouring nodes share blocks -- are numbered by two ballots, their numbers listed in LDS, and
+// fetched by groups of four lanes, one 16-byte quarter each: a block is ONE 64-byte request of one load instruction instead of
+// four quarter requests in four instructions, repeated by every lane that shares it.  (The kernel is bound by the requests its
+// waves issue, not by bytes.)  Word w of the staging area = quarter w & 3 of distinct block w >> 2; lanes then read the blocks
+// they need -- for the four-base ranks and again for the left-extension ranks -- from there.
+constexpr u32 STAGE_BLOCKS = 128;                        // distinct blocks of a tile: at most two per lane
+constexpr u32 WAVE_LDS_WORDS = STAGE_BLOCKS * 4 + 32;    // uint4 per wave: the staged blocks, then the list of their numbers (8.5 KB)
+__device__ __forceinline__ void staged_blk(const uint4* wl, u32 idx, Blk16& r) {
+    const uint4 h = wl[idx * 4 + 0], a = wl[idx * 4 + 1], c = wl[idx * 4 + 2], d = wl[idx * 4 + 3];
+    r.cnt[0] = h.x; r.cnt[1] = h.y; r.cnt[2] = h.z; r.cnt[3] = h.w;
+    r.p0a = ((u64)a.y << 32) | a.x; r.p0b = ((u64)a.w << 32) | a.z;
+    r.p1a = ((u64)c.y << 32) | c.x; r.p1b = ((u64)c.w << 32) | c.z;
+    r.p2a = ((u64)d.y << 32) | d.x; r.p2b = ((u64)d.w << 32) | d.z;
+}
+template <typename P, bool ONESB>
+__device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 idx, u64 x, u32 c) {
+    const uint4 q1 = wl[idx * 4 + 1], q2 = wl[idx * 4 + 2], q3 = wl[idx * 4 + 3];
+    const u32 cntc = reinterpret_cast<const u32*>(wl + idx * 4)[c];
+    return rank_one<P, ONESB>(sa, sbl, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z, ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z,
+                              ((u64)q3.y << 32) | q3.x, ((u64)q3.w << 32) | q3.z, cntc, x, c);
+}
+// the same from memory (positions outside the two blocks a lane holds: intervals over more than two blocks only)
+template <typename P, bool ONESB>
+__device__ __forceinline__ P rank_load(const DevIndex& ix, const SbArgs& sa, const u64* sbl, u64 x, u32 c) {
+    Blk16 b;
+    load_blk(ix.blk, x >> BLK_SHIFT, b);
+    return rank_one<P, ONESB>(sa, sbl, b.p0a, b.p0b, b.p1a, b.p1b, b.p2a, b.p2b, DSM_PICK(b.cnt, c), x, c);
+}
+
+__device__ __forceinline__ u64 lf_wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ u32 lf_bits_below_lane(u64 p) {  // set bits of p below this lane's position
+    return __builtin_amdgcn_mbcnt_hi((u32)(p >> 32), __builtin_amdgcn_mbcnt_lo((u32)p, 0u));
+}
+
+__device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
+    return (u32)((set < 10 ? a.costsum_lo >> (6 * set) : a.costsum_hi >> (6 * (set - 10))) & 63u);
+}
+// the set bits of a 4-bit mask in increasing order, two bits each (masks 0-7 in LO, 8-15 in HI, eight bits per mask)
+__device__ __forceinline__ u32 bit_list(u32 m) {
+    return (u32)(((m & 8u) ? 0xe439380e340d0c03ull : 0x2409080204010000ull) >> (8 * (m & 7u))) & 0xFFu;
+}
+
+// The LF-step kernel.  A wave takes tiles of 64 consecutive nodes of the (colex-ordered) union level.  While a tile is being
+// ranked, the record heads of the wave's next tile and the handles of the one after are already on their way (two-stage software
+// pipeline), so a tile waits for one memory round trip -- its index blocks -- instead of three dependent ones.  Waves never
+// synchronise with each other: a wave's children with symbol c go to the 64 handles  c * seg + 64 * tile ..  of the next record
+// buffer, ranked by ballot.
+// splane receives, per tile, the four bit planes "this sample keeps child c of node j" (the advance kernel derives the
+// children's record handles from them); cnt (single sample only: the union trie is the sample's trie) accumulates the child
+// counts per symbol and 256-node tile for the scan.
+constexpr u32 CREC_WORDS(size_t psize) { return psize == 4 ? 1u : 2u; }  // uint4 per compact record
+
+template <typename P, bool INC>
+struct RecHead;
+template <typename P>
+struct RecHead<P, false> {   // what a lane needs of its record before anything can be ranked (wide format: decoded fields)
+    P sp, ep, e0min, e0max, e1min, e1max;
+    u32 flags;     // bits 0-3: mask of the non-empty left-extension intervals, bit 8: the node is present in this sample
+    u32 r;         // the record's handle (the few nodes with more than two intervals read the others through it)
+};
+template <typename P>
+struct RecHead<P, true> {    // compact format: the raw words, decoded when the tile is worked on
+    uint4 w[sizeof(P) == 4 ? 1 : 2];
+    u32 r;         // handle, DEAD for an absent node
+};
+// Every load of the pipeline is unconditional (absent nodes read record 0 and discard it; the first two interval slots are
+// read whether or not they are in use): a load behind a branch makes the compiler wait for ALL outstanding loads at the join --
+// the prefetches would stop being prefetches -- and one node in ten has two intervals, i.e. nearly every wave has such a lane.
+template <typename P>
+__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, false>& h) {
+    const bool live = r != DEAD;
+    const u32 rr = live ? r : 0u;
+    const P sp = rec[rr], ep = rec[cap + rr];
+    h.e0min = rec[2 * cap + rr]; h.e0max = rec[3 * cap + rr];
+    h.e1min = rec[4 * cap + rr]; h.e1max = rec[5 * cap + rr];
+    const u32 m = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * cap)[rr];
+    h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0;
+    h.flags = live ? (m | 0x100u) : 0u;
+    h.r = rr;
+}
+template <typename P>
+__device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap, u32 r, RecHead<P, true>& h) {
+    const uint4* c = reinterpret_cast<const uint4*>(rec) + (size_t)(r != DEAD ? r : 0u) * CREC_WORDS(sizeof(P));
+    h.w[0] = c[0];
+    if (sizeof(P) == 8) h.w[sizeof(P) == 4 ? 0 : 1] = c[sizeof(P) == 4 ? 0 : 1];
+    h.r = r;
+}
+// decoded view of a head
+template <typename P>
+struct NodeIn {
+    P sp, ep, e0min, e0max, e1min, e1max;
+    u32 emask, r;
+    bool live;
+};
+template <typename P>
+__device__ __forceinline__ void decode_head(const RecHead<P, false>& h, NodeIn<P>& n) {
+    n.sp = h.sp; n.ep = h.ep; n.e0min = h.e0min; n.e0max = h.e0max; n.e1min = h.e1min; n.e1max = h.e1max;
+    n.emask = h.flags & 15u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
+}
+__device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<u32>& n) {
+    const uint4 v = h.w[0];
+    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
+    const u32 sp = v.x;
+    n.sp = n.live ? sp : 1u;
+    n.ep = n.live ? sp + (v.y & 0xFFFFu) : 0u;
+    n.e0min = sp + (v.y >> 16); n.e0max = sp + (v.z & 0xFFFFu);
+    n.e1min = sp + (v.z >> 16); n.e1max = sp + (v.w & 0xFFFFu);
+    n.emask = n.live ? (v.w >> 16) & 15u : 0u;
+}
+__device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<u64>& n) {
+    const uint4 v = h.w[0], x = h.w[1];
+    n.live = h.r != DEAD; n.r = n.live ? h.r : 0u;
+    const u64 sp = ((u64)v.y << 32) | v.x;
+    n.sp = n.live ? sp : 1ull;
+    n.ep = n.live ? sp + (v.z & 0xFFFFu) : 0ull;
+    n.e0min = sp + (v.z >> 16); n.e0max = sp + (v.w & 0xFFFFu);
+    n.e1min = sp + (v.w >> 16); n.e1max = sp + (x.x & 0xFFFFu);
+    n.emask = n.live ? (x.x >> 16) & 15u : 0u;
+}
+// A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions (slots 2, 3 went to the wide fields already)
+template <typename P, bool OUTC>
+__device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32 q, P nsp, P nep, P l0, P h0, P l1, P h1, u32 cn, u32 cm) {
+    if (OUTC) {
+        uint4* c = reinterpret_cast<uint4*>(out) + (size_t)q * CREC_WORDS(sizeof(P));
+        const u32 len = (u32)(nep - nsp), a0 = cn > 0 ? (u32)(l0 - nsp) : 0u, b0 = cn > 0 ? (u32)(h0 - nsp) : 0u,
+                  a1 = cn > 1 ? (u32)(l1 - nsp) : 0u, b1 = cn > 1 ? (u32)(h1 - nsp) : 0u;
+        if (sizeof(P) == 4) {
+            c[0] = make_uint4((u32)nsp, len | (a0 << 16), b0 | (a1 << 16), b1 | (cm << 16));
+        } else {
+            c[0] = make_uint4((u32)nsp, (u32)((u64)nsp >> 32), len | (a0 << 16), b0 | (a1 << 16));
+            c[sizeof(P) == 4 ? 0 : 1] = make_uint4(b1 | (cm << 16), 0u, 0u, 0u);
+        }
+    } else {
+        out[q] = nsp;
+        out[cap + q] = nep;
+        if (cn > 0) { out[2 * cap + q] = l0; out[3 * cap + q] = h0; }
+        if (cn > 1) { out[4 * cap + q] = l1; out[5 * cap + q] = h1; }
+        reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[q] = (u8)cm;
+    }
+}
+
+struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
+    // (k <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
+    u32 kne = 0, ll = 0, lf = 0, rank = 0;
+    u32 rbytes = 0;     // bytes of records read and written
+    u32 wide = 0;       // bit 0: some surviving child has a frequency of 512 or more, bit 1: of 65535 or more (the next level's column format)
+};
+
+// Which tile a wave takes next.  Dynamic: the workgroup's waves share a counter in LDS; draw k of workgroup b is tile
+// ((k / WPB) * G + b) * WPB + k % WPB -- rows of WPB consecutive tiles, G rows apart.  Static (round 3): wave gw of nwaves takes
+// gw, gw + nwaves, ...  A draw past the level's last tile means "no tile"; the draws of a wave increase, so every later one is past it too.
+template <int WPB>
+struct TileSeq {
+    u32* ctr;     // dynamic: the workgroup's counter (LDS)
+    u32 G, b;     // workgroups of the launch, this one
+    u32 last;     // static: the tile drawn last
+    u32 stride;   // static: waves of the launch
+    __device__ __forceinline__ u32 issue() {  // the draw is an LDS atomic: issued here, its value is taken by take()
+        if (!LF_DYNAMIC) return 0u;
+        u32 k = 0;
+        if ((threadIdx.x & 63) == 0) k = atomicAdd(ctr, 1u);
+        return k;
+    }
+    __device__ __forceinline__ u32 take(u32 issued) {
+        if (!LF_DYNAMIC) {
+            const u32 far = ~last < stride ? ~0u : last + stride;  // (saturates: "no tile" stays "no tile")
+            last = far;
+            return far;
+        }
+        const u32 k = (u32)__builtin_amdgcn_readfirstlane((int)issued);
+        return ((k / (u32)WPB) * G + b) * (u32)WPB + k % (u32)WPB;
+    }
+    __device__ __forceinline__ u32 next() { return take(issue()); }
+};
+
+// One tile of 64 nodes.  hc: the heads of this tile (requested one tile ago); hn: receives the heads of the wave's next tile,
+// whose handles are in rn (requested one tile ago); rn then receives the handles of the tile drawn here (tfar: the wave's tile after
+// next).
+// SELF (several samples, no handle table): rp is the level's slot array (4 * parent + base per node, shared by all samples) and a
+// node's handle follows from the planes the sample wrote at the parent level (pplane): child c of the parent at round T, lane j has
+// the handle c * seg + 64 * T + (set bits of plane[T][c] below j), and no handle when the bit is clear.  The pipeline is one stage
+// deeper: slots of the tile three ahead, plane words of the tile two ahead, heads of the next tile.
+struct SelfState {
+    u32 s1 = DEAD, s2 = DEAD;  // slots of the lane's nodes one and two tiles ahead
+    u64 pn = 0;                // plane word for s1
+};
+__device__ __forceinline__ u32 self_handle(u32 slot, u64 plane, u32 seg) {
+    const u32 j = (slot >> 2) & 63u;
+    const bool has = slot != DEAD && ((plane >> j) & 1ull);
+    return has ? (slot & 3u) * seg + ((slot >> 8) << 6) + (u32)__popcll(plane & ((1ull << j) - 1)) : DEAD;
+}
+__device__ __forceinline__ size_t self_plane_index(u32 slot) { return slot != DEAD ? (size_t)(slot >> 8) * 4 + (slot & 3u) : (size_t)0; }
+
+template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF, int WPB>
+__device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, uint4* wl, const u32* __restrict__ rp, const P* __restrict__ rec,
+                                            P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
+                                            u8* __restrict__ pl, const ExpandArgs& a, const u32 t, TileSeq<WPB>& seq, u32& tfar, const u32 ntile,
+                                            const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
+                                            const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab) {
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (1ull << lane) - 1;
+    const size_t cap = a.cap;
+    const u32 i = t * 64 + lane;
+    const u32 drawn = seq.issue();  // (the wave's tile after next, or three ahead: taken where its handles are requested)
+    NodeIn<P> nd;
+    decode_head(hc, nd);
+    const bool live = nd.live;
+    const P sp = nd.sp, ep = nd.ep;
+    const u32 emask = nd.emask;
+    const u32 ne = __popc(emask);
+    u32 keepw = ~0u;  // the word of the keep table that holds this node's frequency (requested here, used at the candidate ballot)
+    const u64 freq1 = (u64)ep - (u64)sp + 1;
+    if (!SELF) keepw = keeptab[(freq1 < KEEP_FREQS ? (u32)freq1 : 0u) >> 5];
+    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;  // blocks of the two interval ends
+    u32 n_lf = 0, n_rank = 0, lines = 0;
+    P Rsp[4], Rep[4];
+    u32 present = 0;  // bit c: child c is emitted
+    u32 idx0, idx1;   // numbers of this lane's two blocks among the tile's distinct blocks
+    u32 rb_out = 0;   // bytes of child records this lane writes
+    {
+        // ---- the distinct blocks of the tile (see the staging note above) ----
+        u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
+        u32 pm = live ? (u32)b1 + 1u : 0u;  // 1 + last block of the lane; running maximum over the lanes below = the last block listed
+        if (!__all(live)) {  // absent nodes in between (several samples, or the last tile): the maximum is carried across them
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(pm, dd, 64); if (lane >= dd) pm = o > pm ? o : pm; }
+        }
+        u32 prev = __shfl_up(pm, 1, 64);  // (every lane present: the blocks increase along the lanes, the lane below holds the maximum)
+        if (lane == 0) prev = 0;
+        const bool f0 = live && (u32)b0 + 1u > prev, f1 = live && b1 != b0;
+        const u64 m0 = __ballot(f0), m1 = __ballot(f1);
+        const u32 D = (u32)__popcll(m0) + (u32)__popcll(m1);
+        const u32 before = lf_bits_below_lane(m0) + lf_bits_below_lane(m1);
+        idx0 = f0 ? before : (before ? before - 1u : 0u);
+        idx1 = f1 ? idx0 + 1u : idx0;
+        if (!live) { idx0 = 0; idx1 = 0; }
+        lines = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+        if (f0) list[idx0] = (u32)b0;
+        if (f1) list[idx1] = (u32)b1;
+        if (D == 0 && lane == 0) list[0] = 0;
+        const u32 Dm1 = D ? D - 1u : 0u;
+        const u32 g = (u32)lane >> 2, qq = (u32)lane & 3u;
+        // four lanes per block, sixteen blocks per instruction; lanes beyond the last block repeat it
+        uint4 v0, v1, v2, v3;
+        {
+            const u32 d0 = g < Dm1 ? g : Dm1, d1 = g + 16 < Dm1 ? g + 16 : Dm1, d2 = g + 32 < Dm1 ? g + 32 : Dm1, d3 = g + 48 < Dm1 ? g + 48 : Dm1;
+            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
+            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
+            v0 = base[(size_t)bb0 * 4 + qq]; v1 = base[(size_t)bb1 * 4 + qq]; v2 = base[(size_t)bb2 * 4 + qq]; v3 = base[(size_t)bb3 * 4 + qq];
+        }
+        if (D > 64) {  // (wave-uniform) the rarer second half
+            const u32 d0 = g + 64 < Dm1 ? g + 64 : Dm1, d1 = g + 80 < Dm1 ? g + 80 : Dm1, d2 = g + 96 < Dm1 ? g + 96 : Dm1, d3 = g + 112 < Dm1 ? g + 112 : Dm1;
+            const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
+            const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
+            const uint4 w0 = base[(size_t)bb0 * 4 + qq], w1 = base[(size_t)bb1 * 4 + qq], w2 = base[(size_t)bb2 * 4 + qq], w3 = base[(size_t)bb3 * 4 + qq];
+            wl[256 + lane] = w0; wl[320 + lane] = w1; wl[384 + lane] = w2; wl[448 + lane] = w3;
+        }
+        // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
+        // the blocks leaves them in flight) ----
+        tfar = seq.take(drawn);
+        {
+            const u32 ifar = tfar * 64 + lane;
+            const bool infar = tfar < ntile && ifar < a.F;
+            if (SELF) {
+                load_head<P>(rec, cap, self_handle(ss->s1, ss->pn, a.seg), hn);
+                ss->pn = pplane[self_plane_index(ss->s2)];
+                ss->s1 = ss->s2;
+                const u32 v = rp[infar ? ifar : 0u];
+                ss->s2 = infar ? v : DEAD;
+            } else {
+                load_head<P>(rec, cap, rn, hn);
+                const u32 v = rp[infar ? ifar : 0u];
+                rn = infar ? v : DEAD;
+            }
+        }
+        wl[lane] = v0; wl[64 + lane] = v1; wl[128 + lane] = v2; wl[192 + lane] = v3;
+        asm volatile("" ::: "memory");  // the blocks are read back from LDS (other lanes' words among them)
+        // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty.
+        Blk16 r0;
+        staged_blk(wl, idx0, r0);
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)sp, Rsp);  // LF(c, sp-1)
+        const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
+        staged_blk(wl, idx1, r0);
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
+        const bool single = (a.symbol_phase & 1u) && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
+        u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((a.allowed >> c) & 1u) {
+                const P nsp = Rsp[c], nep = Rep[c] - 1;
+                if (nsp <= nep) {
+                    nonempty |= 1u << c;
+                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
+                        present |= 1u << c;
+                        if ((u64)(nep - nsp) + 1 >= PACK_FMAX) acc.wide |= (u64)(nep - nsp) + 1 >= 65535 ? 3u : 1u;
+                    }
+                }
+            }
+        }
+        // What the reference would have spent on this node: two LF per attempted base (Query::pushChar, Query.h:37-45) and two per
+        // left-extension interval for every base whose interval is non-empty; BitRank::rank calls = LF calls weighted by the
+        // base's code length (a.costsum: the sums per set of bases, six bits each).
+        n_lf = 2 * (u32)__popc(a.allowed) + 2 * ne * (u32)__popc(nonempty);
+        n_rank = 2 * costsum(a, a.allowed) + 2 * ne * costsum(a, nonempty);
+        if (__any(single)) {  // nodes of frequency 1 follow one branch by getL instead (only reachable with fmin = 1)
+            if (single) {
+                const bool go = a.allowed && ((nonempty >> lcode) & 1u) && lcode < 4;
+                n_lf = go ? 2 * ne + 2 : 0u;
+                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * DSM_PICK(a.cost, lcode) : 0u);
+            }
+        }
+        if (!live) { n_lf = 0; n_rank = 0; present = 0; }
+    }
+    // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
+    const u32 k = __popc(present);
+    u64 bal[4];
+    u32 qa[4];  // handle of this lane's child with symbol c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bal[c] = __ballot((present >> c) & 1u);
+        qa[c] = (u32)c * a.seg + t * 64 + (u32)__popcll(bal[c] & lt);
+    }
+    if (lane < 4) {
+        const u64 b = DSM_PICK(bal, lane);
+        if (!(a.symbol_phase & 8u)) splane[(size_t)t * 4 + lane] = b;
+        const u32 nb = (u32)__popcll(b);
+        if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
+    }
+    // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
+    bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
+    if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
+        if (ne > 2) {
+#pragma unroll
+            for (int e = 2; e < 4; ++e)
+                if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * cap + nd.r] == sp && rec[(size_t)(3 + 2 * e) * cap + nd.r] == ep) matches = true;
+        }
+    }
+    const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
+    if (a.symbol_phase & 8u) {  // one sample: planes and the level's candidates in one line per tile (the advance sweep reads it)
+        // metaserver.cpp:406-419 for a node with one reader: not a single child (416-417), no single left char (383-387, 418)
+        const bool ekeep = SELF || freq1 >= KEEP_FREQS || ((keepw >> ((u32)freq1 & 31u)) & 1u);  // the exact entropy verdict for this frequency
+        const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u) && ekeep);
+        if (lane < 6) {
+            const u64 nc = (u64)__popcll(cb);
+            const u64 word = lane < 4 ? DSM_PICK(bal, lane) : (lane == 4 ? cb : (nc | (nc << 32)));
+            splane[(size_t)t * 8 + lane] = word;
+        }
+    }
+    // ---- child records.  A lane's work is the list of its (child, left-extension interval) pairs, child-major: most lanes have
+    // one pair, one in ten has two, so a wave runs about two rounds instead of (most children) x (most intervals).  Per pair: LF
+    // with the child's base at both ends of the parent's interval (EnumerateQuery.cpp:44-55) -- an end that coincides with sp or
+    // ep + 1 is the child's own end -- and the child keeps the interval if it stays non-empty, compacted into its first slots.
+    // The ends lie inside [sp, ep + 1], i.e. in one of the two parked blocks unless the interval spans more than two blocks.
+    {
+        const u32 ne1 = ne ? ne : 1u;
+        const u32 npair = k * ne1;
+        const u32 cjpack = bit_list(present), kkpack = bit_list(emask);  // two bits per slot: bases of the children / of the intervals, in order
+        u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
+        P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
+        P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
+        rb_out = 0;
+#pragma nounroll
+        for (u32 p = 0; __any(p < npair); ++p) {
+            const bool act = p < npair;
+            const u32 j = ne1 == 1 ? p : (ne1 == 2 ? p >> 1 : (ne1 == 4 ? p >> 2 : (p * 11u) >> 5));  // p / ne1 for p < 16
+            const u32 e = p - j * ne1;
+            const u32 c = (cjpack >> (2 * j)) & 3u, kk = (kkpack >> (2 * e)) & 3u;
+            const u32 q = DSM_PICK(qa, c);
+            const P nsp = DSM_PICK(Rsp, c), nep1 = DSM_PICK(Rep, c);  // the child's interval is [nsp, nep1 - 1]
+            if (e == 0) { cn = 0; cm = 0; }
+            const bool hasext = act && ne > 0;
+            P xmin = e == 0 ? nd.e0min : nd.e1min, xmax = e == 0 ? nd.e0max : nd.e1max;
+            if (__any(hasext && e > 1)) {
+                if (hasext && e > 1) {
+                    xmin = rec[(size_t)(2 + 2 * e) * cap + nd.r];
+                    xmax = rec[(size_t)(3 + 2 * e) * cap + nd.r];
+                }
+            }
+            const u64 xl = hasext ? (u64)xmin : (u64)sp, xh = hasext ? (u64)xmax + 1 : (u64)ep + 1;
+            P l = nsp, h = nep1;
+            bool needl = xl != (u64)sp;
+            const bool needh = xh != (u64)ep + 1;
+            if (e > 0 && xl == prevx) { l = prevh; needl = false; }  // adjacent intervals share an end: the rank is the previous pair's
+            if (__any(needl)) {
+                if (needl) {
+                    const u64 bl = xl >> BLK_SHIFT;
+                    if (bl == b0 || bl == b1) l = rank_staged<P, ONESB>(a.sb, sbl, wl, bl != b0 ? idx1 : idx0, xl, c);
+                    else { l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c); ++lines; }
+                }
+            }
+            if (__any(needh)) {
+                if (needh) {
+                    const u64 bh = xh >> BLK_SHIFT;
+                    if (bh == b0 || bh == b1) h = rank_staged<P, ONESB>(a.sb, sbl, wl, bh != b0 ? idx1 : idx0, xh, c);
+                    else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
+                }
+            }
+            prevx = (P)xh; prevh = h;
+            if (hasext && l <= h - 1) {
+                if (cn == 0) { kl0 = l; kh0 = h - 1; }
+                else if (cn == 1) { kl1 = l; kh1 = h - 1; }
+                else { out[(size_t)(2 + 2 * cn) * cap + q] = l; out[(size_t)(3 + 2 * cn) * cap + q] = h - 1; }  // slots 2, 3: wide fields
+                ++cn;
+                cm |= 1u << kk;
+            }
+            if (act && e == ne1 - 1) {
+                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
+                rb_out += (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1) + (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P)) +
+                          (cn > 2 ? (cn - 2) * 2u * (u32)sizeof(P) : 0u);
+            }
+        }
+    }
+    if (i < a.F) {
+        // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
+        if (a.w16 == 2) {
+            reinterpret_cast<u16*>(valf)[(size_t)i * a.cstride] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
+        } else {
+            if (a.w16) reinterpret_cast<u16*>(valf)[i] = live ? (u16)(ep - sp + 1) : (u16)0;
+            else valf[i] = live ? (P)(ep - sp + 1) : (P)0;
+            pl[i] = (u8)(present | (mycode << 4));
+        }
+    }
+    acc.kne += (a.symbol_phase & 2u) ? k : 0u; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
+    // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
+    // when in use) and its children's (compact word each, or their fields; rb_out collected by the rounds)
+    acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
+}
+
+// One sample's LF-step sweep over a level: the body of expand_kernel (one sample per launch) and of expand_batch_kernel.
+// tile_ctr: the workgroup's tile counter in LDS, zero when the sweep starts (the caller's barrier).
+template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF>
+__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, const u32* __restrict__ rp, const P* __restrict__ rec,
+                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
+                                             u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
+                                             unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane) {
+    constexpr int WPB = LfShape<P>::WPB;
+    uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
+    if (!ONESB) {
+        const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
+        for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
+    }
+    if (LF_DYNAMIC && threadIdx.x == 0) *tile_ctr = 0;
+    if (!ONESB || LF_DYNAMIC) __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6)));
+    const u32 ntile = (a.F + 63) >> 6;
+    const u32* keeptab = reinterpret_cast<const u32*>(counters + (size_t)COUNTER_SHARDS * 8);  // (see KEEP_FREQS)
+    ExpandAcc acc;
+#ifdef DSM_CLOCK_PROBE
+    const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
+#endif
+    TileSeq<WPB> seq;
+    seq.ctr = tile_ctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
+    u32 tA, tB, tC = ~0u;
+    if (LF_DYNAMIC) { tA = seq.next(); tB = seq.next(); if (SELF) tC = seq.next(); }
+    else {
+        tA = gw; tB = ~gw < seq.stride ? ~0u : gw + seq.stride;
+        seq.last = tB;
+        if (SELF) tC = seq.next();
+    }
+    {
+        // prologue of the pipeline: heads of the wave's first tile, handles of its second
+        u32 rn = DEAD;
+        u32 r0 = DEAD;
+        const u32 i0 = tA * 64 + lane, i1 = tB * 64 + lane;
+        if (tA < ntile && i0 < a.F) r0 = rp[i0];
+        if (tB < ntile && i1 < a.F) rn = rp[i1];
+        SelfState ss;
+        if (SELF) {  // r0, rn hold slots here: handles of the first tile now, the deeper stages primed
+            const u32 i2 = tC * 64 + lane;
+            ss.s1 = rn;
+            if (tC < ntile && i2 < a.F) ss.s2 = rp[i2];
+            const u64 p0 = pplane[self_plane_index(r0)];
+            ss.pn = pplane[self_plane_index(ss.s1)];
+            r0 = self_handle(r0, p0, a.seg);
+        }
+        RecHead<P, INC> hA, hB;
+        load_head<P>(rec, a.cap, r0, hA);
+        // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied.
+        // t0 / t1 / t2: the wave's current tile and the ones whose heads / slots are on their way (t2: SELF only).
+        u32 t0 = tA, t1 = tB, t2 = tC, tf = ~0u;
+        while (t0 < ntile) {
+            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hA, hB, rn, acc, pplane, &ss, keeptab);
+            t0 = t1;
+            if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
+            if (t0 >= ntile) break;
+            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hB, hA, rn, acc, pplane, &ss, keeptab);
+            t0 = t1;
+            if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
+        }
+    }
+#ifdef DSM_CLOCK_PROBE
+    if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
+        atomicAdd((unsigned long long*)&counters[6], (unsigned long long)(__builtin_readcyclecounter() - probe_c0));
+        atomicAdd((unsigned long long*)&counters[7], (unsigned long long)(wall_clock64() - probe_r0));
+    }
+    if (lane == 0 && tA < ntile) {  // every wave with tiles: its start and end (100 MHz ticks): earliest, latest and sum of both, per launch (three shards)
+        const unsigned long long e1 = (unsigned long long)wall_clock64(), s1 = (unsigned long long)probe_r0;
+        unsigned long long* q = (unsigned long long*)&counters[(size_t)a.probe_slot * 8];
+        atomicMax(q + 6, ~s1); atomicMax(q + 7, s1);
+        atomicMax(q + 8 + 6, ~e1); atomicMax(q + 8 + 7, e1);
+        atomicAdd(q + 16 + 6, s1 & 0xFFFFFFFFull); atomicAdd(q + 16 + 7, e1 & 0xFFFFFFFFull);
+    }
+#endif
+    // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
+    if (__any(acc.wide != 0) && lane == 0) atomicMax(childmax, __any((acc.wide & 2u) != 0) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
+    {
+        u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
+#pragma unroll
+        for (int q = 0; q < NCOUNTERS; ++q) v[q] = lf_wave_sum_u64(v[q]);
+        if (lane < NCOUNTERS) {
+            u64 mine = v[0];
+#pragma unroll
+            for (int q = 1; q < NCOUNTERS; ++q) mine = lane == q ? v[q] : mine;
+            if (mine) atomicAdd((unsigned long long*)&counters[(size_t)(gw & (COUNTER_SHARDS - 1)) * 8 + lane], (unsigned long long)mine);
+        }
+    }
+}
+
+// (32-bit positions fit four waves per SIMD without spilling when the allocator is told to aim for it; 64-bit positions take three)
+template <typename P, bool ONESB, bool INC, bool OUTC>
+__global__ __launch_bounds__(LfShape<P>::WPB * 64) __attribute__((amdgpu_waves_per_eu(LfShape<P>::WAVES_PER_SIMD)))
+void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt,
+                   P* __restrict__ valf, u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
+    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
+    __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
+    __shared__ u32 tile_ctr;
+    if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
+        const u32 F = a.dyn[0], cls = a.dyn[1];
+        if ((cls & a.dyn_mask) != a.dyn_expect || F > a.fcap || F == 0) return;
+        a.F = F;
+        a.nbp = (F + TILE - 1) / TILE;
+        if (a.w16 != 2) pl = reinterpret_cast<u8*>(valf) + (size_t)F * (a.w16 ? 2u : (u32)sizeof(P));  // one sample: the flag bytes follow its frequencies
+        if (a.nbp <= 1) cnt = nullptr;
+    }
+    expand_sweep<P, ONESB, INC, OUTC, false>(ix, sbl, parked, &tile_ctr, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax, nullptr);
+}
+
+template <typename P, bool ONESB, bool INC, bool OUTC>
+__global__ __launch_bounds__(LfShape<P>::WPB * 64) __attribute__((amdgpu_waves_per_eu(LfShape<P>::WAVES_PER_SIMD)))
+void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
+    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
+    __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
+    __shared__ u32 tile_ctr;
+    const ExpandSample& S = b.s[blockIdx.y];
+    a.sb = S.sb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.cost[c] = S.cost[c];
+    a.access_pack = S.access_pack;
+    a.costsum_lo = S.costsum_lo;
+    a.costsum_hi = S.costsum_hi;
+    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename P>
+static int geometry_t(int device, LfGeometry* g) {
+    int cus = 0, per = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return fail(DSM_E_HIP, "hipDeviceGetAttribute failed");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (expand_kernel<P, true, true, true>), LfShape<P>::WPB * 64, 0) != hipSuccess)
+        return fail(DSM_E_HIP, "hipOccupancyMaxActiveBlocksPerMultiprocessor failed");
+    if (const char* e = getenv("DSM_EXPAND_BLOCKS_PER_CU")) per = atoi(e);
+    if (per < 1) per = 1;
+    g->blocks = (u32)(cus > 0 ? cus : 256) * (u32)per;
+    g->waves_per_block = (u32)LfShape<P>::WPB;
+    return 0;
+}
+int lf_step_geometry(bool wide_pos, int device, LfGeometry* g) { return wide_pos ? geometry_t<u64>(device, g) : geometry_t<u32>(device, g); }
+
+template <typename P, bool SB, bool IC, bool OC>
+static void launch1(dim3 grid, hipStream_t st, const DevIndex& ix, const u32* rp, const void* rec, void* out, u64* splane, u32* cnt, void* valf, u8* pl,
+                    const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
+    hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P>::WPB * 64), 0, st, ix, rp, (const P*)rec, (P*)out, splane, cnt, (P*)valf, pl, a, counters,
+                       childmax);
+}
+template <typename P, bool SB, bool IC, bool OC>
+static void launchb(dim3 grid, hipStream_t st, const ExpandBatch& b, const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
+    hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P>::WPB * 64), 0, st, b, a, counters, childmax);
+}
+// (the formats are template parameters: eight instantiations per position type)
+#define DSM_LF_DISPATCH(FN, P, ...)                                                             \
+    do {                                                                                        \
+        const int key_ = (c.one_sb ? 4 : 0) | (c.fmt_in ? 2 : 0) | (c.fmt_out ? 1 : 0);         \
+        switch (key_) {                                                                         \
+            case 0: FN<P, false, false, false>(__VA_ARGS__); break;                             \
+            case 1: FN<P, false, false, true>(__VA_ARGS__); break;                              \
+            case 2: FN<P, false, true, false>(__VA_ARGS__); break;                              \
+            case 3: FN<P, false, true, true>(__VA_ARGS__); break;                               \
+            case 4: FN<P, true, false, false>(__VA_ARGS__); break;                              \
+            case 5: FN<P, true, false, true>(__VA_ARGS__); break;                               \
+            case 6: FN<P, true, true, false>(__VA_ARGS__); break;                               \
+            default: FN<P, true, true, true>(__VA_ARGS__); break;                               \
+        }                                                                                       \
+    } while (0)
+
+void lf_step_launch(const LfConfig& c, const LfGeometry& g, u64 tiles_bound, hipStream_t st, const DevIndex& ix, const u32* rp, const void* rec, void* out,
+                    u64* splane, u32* cnt, void* valf, u8* pl, const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
+    u64 need = (tiles_bound + g.waves_per_block - 1) / g.waves_per_block;  // workgroups that get a tile at all
+    if (need < 1) need = 1;
+    const dim3 grid((u32)(need < g.blocks ? need : g.blocks));
+    if (c.wide_pos) DSM_LF_DISPATCH(launch1, u64, grid, st, ix, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
+    else DSM_LF_DISPATCH(launch1, u32, grid, st, ix, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
+}
+
+void lf_step_launch_batch(const LfConfig& c, const LfGeometry& g, u32 grid_factor, int nb, hipStream_t st, const ExpandBatch& b, const ExpandArgs& a, u64* counters,
+                          unsigned long long* childmax) {
+    // (measured with eight samples and round 3's workgroups of four waves: 2 x resident -> 1255, 4 x -> 1219, 8 x -> 1189, 16 x -> 1184, 32 x -> 1198 ms per
+    // pass: the samples' sweeps finish unevenly, shorter strides even them out)
+    const u32 ntile = (a.F + 63) >> 6;
+    u32 need = (ntile + g.waves_per_block - 1) / g.waves_per_block;
+    if (need < 1) need = 1;
+    u32 gx = (grid_factor ? grid_factor : 1u) * g.blocks / (u32)nb;
+    if (gx < 1) gx = 1;
+    const dim3 grid(need < gx ? need : gx, (u32)nb);
+    if (c.wide_pos) DSM_LF_DISPATCH(launchb, u64, grid, st, b, a, counters, childmax);
+    else DSM_LF_DISPATCH(launchb, u32, grid, st, b, a, counters, childmax);
+}
+
+}  // namespace dsm
