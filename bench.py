@@ -368,14 +368,24 @@ def main():
     if os.environ.get("DSM_BENCH_WATCHDOG"):  # rehearsal aid: dump every thread's stack if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DSM_BENCH_WATCHDOG"]), exit=True)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (one rank per GPU) before
+        # anything here has touched the GPU, and leave with its exit code.  (Never exec from a process that has initialised HIP.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != args.gpus:  # under a launcher its world size counts
+        args.gpus = world
     ndev = torch.cuda.device_count()
     local = local % max(1, ndev)  # rehearsals with more ranks than cards (DSM_BENCH_BACKEND=gloo) share a card
     torch.cuda.set_device(local)

@@ -1890,6 +1890,8 @@ class Engine {
     u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced -> scanned offsets
     u32* cntraw = nullptr;                     // single sample: the counts as the expand kernel accumulates them (kept zero between levels)
     LfGeometry lfgeo{256, 16};                 // resident workgroups of the LF-step kernel and their waves (expand.hip)
+    u32* d_rowctr = nullptr;                   // the LF-step launches' row counters: two sets, used alternately (ExpandArgs::rowctr)
+    u32 lf_sel = 0;
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8* samechild = nullptr;
@@ -2085,6 +2087,8 @@ class Engine {
             DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
         }
         if (int rc = lf_step_geometry(sizeof(P) == 8, device, &lfgeo)) return rc;  // (all waves of an LF-step launch are resident)
+        if (int rc = dalloc(d_rowctr, (size_t)2 * LF_ROWCTRS)) return rc;
+        DSM_HIP(hipMemset(d_rowctr, 0, 2 * LF_ROWCTRS * sizeof(u32)));
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
@@ -2219,6 +2223,7 @@ class Engine {
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
         if (cntraw) DSM_HIP(hipMemsetAsync(cntraw, 0, (4 * (size_t)(Seg / TILE) + 8) * sizeof(u32), st));  // a run that failed mid-level may have left counts
+        DSM_HIP(hipMemsetAsync(d_rowctr, 0, 2 * LF_ROWCTRS * sizeof(u32), st));
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -2396,6 +2401,7 @@ class Engine {
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;
                     static const u32 grid_factor = getenv("DSM_BATCH_GRID_FACTOR") ? (u32)atoi(getenv("DSM_BATCH_GRID_FACTOR")) : 8u;
                     lc.one_sb = all_one_sb;
+                    ea.rowctr = d_rowctr; ea.rowsel = lf_sel; lf_sel ^= 1u;
                     lf_step_launch_batch(lc, lfgeo, grid_factor ? grid_factor : 8u, nb, st, eb, ea, d_counters, d_childmax);
                     nb = 0;
                     ++stats.expand_launches;
@@ -2409,6 +2415,7 @@ class Engine {
                 u32* ecnt = (d == 1 && (ea.nbp > 1 || dynamic)) ? cntraw : (u32*)nullptr;
                 // (a launch queued ahead: Fmax bounds the level -- four children per node of the level before it)
                 const u64 tiles_bound = dynamic ? (Fmax == ~0ull ? ~0ull >> 8 : (Fmax + 63) / 64) : ((u64)F + 63) / 64;
+                ea.rowctr = d_rowctr; ea.rowsel = lf_sel; lf_sel ^= 1u;
                 lf_step_launch(lc, lfgeo, tiles_bound, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, es.valf, es.pl, ea, d_counters,
                                d_childmax);
                 ++stats.expand_launches;
@@ -2751,6 +2758,21 @@ class Engine {
             DSM_HIP(hipMemcpy(sh.data(), d_counters, sh.size() * sizeof(u64), hipMemcpyDeviceToHost));
             for (int k = 0; k < COUNTER_SHARDS; ++k)
                 for (int c = 0; c < NCOUNTERS; ++c) hc[c] += sh[(size_t)k * 8 + c];
+#ifdef DSM_CLOCK_PROBE
+            if (sh[7]) {  // (expand.hip built with the same flag: per launch the earliest / latest wave start and end, and their sums)
+                double dur = 0, ramp = 0, tail = 0, meanbusy = 0;
+                int nl = 0;
+                const double W = (double)lfgeo.blocks * lfgeo.waves_per_block;
+                for (int k = 1; k + 2 < COUNTER_SHARDS; k += 3) {
+                    const u64 s0 = ~sh[(size_t)k * 8 + 6], s9 = sh[(size_t)k * 8 + 7], e0 = ~sh[(size_t)(k + 1) * 8 + 6], e9 = sh[(size_t)(k + 1) * 8 + 7];
+                    if (!s9 || e9 - s0 < 5000) continue;   // launches of 50 us or more
+                    const double ms = (double)sh[(size_t)(k + 2) * 8 + 6] / W, me = (double)sh[(size_t)(k + 2) * 8 + 7] / W;  // (low 32 bits of the ticks, summed)
+                    dur += (double)(e9 - s0); ramp += (double)(s9 - s0); tail += (double)(e9 - e0); meanbusy += me - ms; ++nl;
+                }
+                fprintf(stderr, "clock probe: %.1f MHz; %d launches >= 50 us: duration %.2f ms, first-to-last wave start %.2f ms, first-to-last wave end %.2f ms, mean wave busy %.2f ms\n",
+                        (double)sh[6] / (double)sh[7] * 100.0, nl, dur * 1e-5, ramp * 1e-5, tail * 1e-5, meanbusy * 1e-5);
+            }
+#endif
         }
         stats.reported += hc[0];
         stats.lf_steps += hc[1];

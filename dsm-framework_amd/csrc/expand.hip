@@ -22,6 +22,10 @@ constexpr bool LF_DYNAMIC = false;   // round 3's distribution: 256-thread workg
 #else
 constexpr bool LF_DYNAMIC = true;
 #endif
+#ifndef DSM_LF_FIXED_PCT
+#define DSM_LF_FIXED_PCT 70
+#endif
+constexpr u32 LF_FIXED_SHARE_PCT = DSM_LF_FIXED_PCT;  // share of a level's rows that the workgroups take in a fixed pattern (see TileSeq)
 template <typename P>
 struct LfShape {
     static constexpr int WAVES_PER_SIMD = sizeof(P) == 4 ? 4 : 3;   // 128 / 168 vector registers
@@ -222,20 +226,40 @@ struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
     u32 wide = 0;       // bit 0: some surviving child has a frequency of 512 or more, bit 1: of 65535 or more (the next level's column format)
 };
 
-// Which tile a wave takes next.  Dynamic: the workgroup's waves share a counter in LDS; draw k of workgroup b is tile
-// ((k / WPB) * G + b) * WPB + k % WPB -- rows of WPB consecutive tiles, G rows apart.  Static (round 3): wave gw of nwaves takes
-// gw, gw + nwaves, ...  A draw past the level's last tile means "no tile"; the draws of a wave increase, so every later one is past it too.
+// Which tile a wave takes next.
+// Dynamic, two levels.  (1) The workgroup's waves share a draw counter in LDS: draw k is slot k % WPB of the workgroup's local row
+// k / WPB, a row being WPB consecutive tiles.  (2) Which row of the level a local row j is: the first jstat rows of every
+// workgroup are fixed (row j * G + b, G = workgroups of the launch), the rest -- about the last third of the level -- are handed out
+// by a counter in global memory, so that the CUs that got through their fixed share early (the XCDs differ by 10-20 %, and a
+// level of a few rows per CU does not divide evenly) take more of it.  A draw from global memory takes microseconds: the wave that
+// draws slot 0 of local row j requests the row for j + 2 and publishes it, one tile later, in a ring in LDS that the draws of that
+// row read (and wait for, if they come early).  The counter belongs to the launch: launches alternate between two sets, and a
+// launch clears the set the next one will use.
+// Static (round 3): wave gw of nwaves takes gw, gw + nwaves, ...
+// A draw past the level's last tile means "no tile"; the draws of a wave increase, so every later one is past it too.
+constexpr u32 ROW_RING = 16;
 template <int WPB>
 struct TileSeq {
-    u32* ctr;     // dynamic: the workgroup's counter (LDS)
-    u32 G, b;     // workgroups of the launch, this one
-    u32 last;     // static: the tile drawn last
-    u32 stride;   // static: waves of the launch
+    u32* ctr;                   // dynamic: the workgroup's draw counter (LDS)
+    unsigned long long* ring;   // dynamic: [ROW_RING] local row << 32 | the global counter's answer for it (LDS)
+    u32* rowctr;                // dynamic: this launch's row counter (global)
+    u32 G, b;                   // workgroups of the launch, this one
+    u32 jstat;                  // local rows below this are fixed
+    u32 pend_j = ~0u, pend_v = 0;  // a row requested from the global counter and not yet published (pend_v: lane 0)
+    u32 last;                   // static: the tile drawn last
+    u32 stride;                 // static: waves of the launch
     __device__ __forceinline__ u32 issue() {  // the draw is an LDS atomic: issued here, its value is taken by take()
         if (!LF_DYNAMIC) return 0u;
         u32 k = 0;
         if ((threadIdx.x & 63) == 0) k = atomicAdd(ctr, 1u);
         return k;
+    }
+    __device__ __forceinline__ void publish() {
+        if (pend_j != ~0u) {
+            if ((threadIdx.x & 63) == 0)
+                __hip_atomic_store(ring + (pend_j & (ROW_RING - 1)), ((unsigned long long)pend_j << 32) | pend_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pend_j = ~0u;
+        }
     }
     __device__ __forceinline__ u32 take(u32 issued) {
         if (!LF_DYNAMIC) {
@@ -244,7 +268,25 @@ struct TileSeq {
             return far;
         }
         const u32 k = (u32)__builtin_amdgcn_readfirstlane((int)issued);
-        return ((k / (u32)WPB) * G + b) * (u32)WPB + k % (u32)WPB;
+        const u32 j = k / (u32)WPB, s = k % (u32)WPB;
+        publish();  // (what this wave requested a tile ago; before it may wait for a row itself)
+        if (s == 0 && j + 2 >= jstat) {
+            if ((threadIdx.x & 63) == 0) pend_v = atomicAdd(rowctr, 1u);
+            pend_j = j + 2;
+        }
+        u32 row = j * G + b;
+        if (j >= jstat) {
+            unsigned long long e;
+            u32 spins = 0;
+            for (;;) {
+                e = __hip_atomic_load(ring + (j & (ROW_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((u32)(e >> 32) == j) break;
+                if (++spins > (1u << 24)) __builtin_trap();  // (a row that never arrives would hang the card: fail loudly instead)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            row = jstat * G + (u32)__builtin_amdgcn_readfirstlane((int)(u32)e);
+        }
+        return row * (u32)WPB + s;
     }
     __device__ __forceinline__ u32 next() { return take(issue()); }
 };
@@ -318,11 +360,21 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         const u32 g = (u32)lane >> 2, qq = (u32)lane & 3u;
         // four lanes per block, sixteen blocks per instruction; lanes beyond the last block repeat it
         uint4 v0, v1, v2, v3;
+#if defined(DSM_LF_SENS_GATHER) || defined(DSM_LF_SENS_STREAM)
+        uint4 sens0 = make_uint4(0, 0, 0, 0), sens1 = sens0, sens2 = sens0, sens3 = sens0;
+#endif
         {
             const u32 d0 = g < Dm1 ? g : Dm1, d1 = g + 16 < Dm1 ? g + 16 : Dm1, d2 = g + 32 < Dm1 ? g + 32 : Dm1, d3 = g + 48 < Dm1 ? g + 48 : Dm1;
             const u32 bb0 = list[d0], bb1 = list[d1], bb2 = list[d2], bb3 = list[d3];
             const uint4* base = reinterpret_cast<const uint4*>(ix.blk);
             v0 = base[(size_t)bb0 * 4 + qq]; v1 = base[(size_t)bb1 * 4 + qq]; v2 = base[(size_t)bb2 * 4 + qq]; v3 = base[(size_t)bb3 * 4 + qq];
+#ifdef DSM_LF_SENS_GATHER  // sensitivity probe: every distinct block is fetched a second time from an unrelated place of the index
+            {
+                const u32 nb = (u32)ix.nblk, o = nb / 2 + 12345u;
+                const u32 c0 = (bb0 + o) % nb, c1 = (bb1 + o) % nb, c2 = (bb2 + o) % nb, c3 = (bb3 + o) % nb;
+                sens0 = base[(size_t)c0 * 4 + qq]; sens1 = base[(size_t)(d1 == d0 ? c0 : c1) * 4 + qq]; sens2 = base[(size_t)(d2 == d1 ? c0 : c2) * 4 + qq]; sens3 = base[(size_t)(d3 == d2 ? c0 : c3) * 4 + qq];
+            }
+#endif
         }
         if (D > 64) {  // (wave-uniform) the rarer second half
             const u32 d0 = g + 64 < Dm1 ? g + 64 : Dm1, d1 = g + 80 < Dm1 ? g + 80 : Dm1, d2 = g + 96 < Dm1 ? g + 96 : Dm1, d3 = g + 112 < Dm1 ? g + 112 : Dm1;
@@ -345,6 +397,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                 ss->s2 = infar ? v : DEAD;
             } else {
                 load_head<P>(rec, cap, rn, hn);
+#ifdef DSM_LF_SENS_STREAM  // sensitivity probe: 16 more bytes per node streamed in (the lines the children's records will be written to)
+                sens0 = reinterpret_cast<const uint4*>(out)[(size_t)(rn != DEAD ? rn : 0u)];
+#endif
                 const u32 v = rp[infar ? ifar : 0u];
                 rn = infar ? v : DEAD;
             }
@@ -358,6 +413,23 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
         staged_blk(wl, idx1, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
+#ifdef DSM_LF_SENS_VALU  // sensitivity probe: the two four-base ranks a second time (about 110 vector instructions per tile more)
+        {
+            u32 i0b = idx0, i1b = idx1;
+            asm volatile("" : "+v"(i0b), "+v"(i1b));
+            P R2[4], R3[4];
+            Blk16 rr;
+            staged_blk(wl, i0b, rr);
+            rank4_blk<P, ONESB>(a.sb, sbl, rr, (u64)sp, R2);
+            staged_blk(wl, i1b, rr);
+            rank4_blk<P, ONESB>(a.sb, sbl, rr, (u64)ep + 1, R3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (R2[c] != Rsp[c] || R3[c] != Rep[c]) acc.wide |= 4u;
+        }
+#endif
+#if defined(DSM_LF_SENS_GATHER) || defined(DSM_LF_SENS_STREAM)
+        if ((sens0.x ^ sens1.y ^ sens2.z ^ sens3.w) == 0x9e3779b9u && sens0.w == 0x7f4a7c15u) acc.wide |= 4u;  // (never: the loads must stay)
+#endif
         const bool single = (a.symbol_phase & 1u) && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
         u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
 #pragma unroll
@@ -505,7 +577,8 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
 // One sample's LF-step sweep over a level: the body of expand_kernel (one sample per launch) and of expand_batch_kernel.
 // tile_ctr: the workgroup's tile counter in LDS, zero when the sweep starts (the caller's barrier).
 template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF>
-__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, const u32* __restrict__ rp, const P* __restrict__ rec,
+__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, unsigned long long* row_ring, u32* rowctr,
+                                             const u32* __restrict__ rp, const P* __restrict__ rec,
                                              P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                              u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
                                              unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane) {
@@ -516,6 +589,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
     }
     if (LF_DYNAMIC && threadIdx.x == 0) *tile_ctr = 0;
+    if (LF_DYNAMIC && threadIdx.x < ROW_RING) row_ring[threadIdx.x] = ~0ull;
     if (!ONESB || LF_DYNAMIC) __syncthreads();
     const int lane = threadIdx.x & 63;
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6)));
@@ -526,7 +600,12 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
     TileSeq<WPB> seq;
-    seq.ctr = tile_ctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
+    seq.ctr = tile_ctr; seq.ring = row_ring; seq.rowctr = rowctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
+    {   // the fixed share: 0.7 of the level's rows, and the rows the prologue draws in any case
+        const u32 rows = (ntile + (u32)WPB - 1) / (u32)WPB;
+        const u32 js = (u32)(((u64)rows * LF_FIXED_SHARE_PCT / 100u) / gridDim.x);
+        seq.jstat = js < 3u ? 3u : js;
+    }
     u32 tA, tB, tC = ~0u;
     if (LF_DYNAMIC) { tA = seq.next(); tB = seq.next(); if (SELF) tC = seq.next(); }
     else {
@@ -564,6 +643,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
             t0 = t1;
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
         }
+        seq.publish();  // (a row this wave still owes the others)
     }
 #ifdef DSM_CLOCK_PROBE
     if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
@@ -601,6 +681,8 @@ void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict_
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
+    __shared__ unsigned long long row_ring[ROW_RING];
+    if (LF_DYNAMIC && blockIdx.x == 0 && threadIdx.x == 0) a.rowctr[(a.rowsel ^ 1u) * LF_ROWCTRS] = 0;  // the next launch's counter (also by a launch that finds nothing to do)
     if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
         const u32 F = a.dyn[0], cls = a.dyn[1];
         if ((cls & a.dyn_mask) != a.dyn_expect || F > a.fcap || F == 0) return;
@@ -609,7 +691,7 @@ void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict_
         if (a.w16 != 2) pl = reinterpret_cast<u8*>(valf) + (size_t)F * (a.w16 ? 2u : (u32)sizeof(P));  // one sample: the flag bytes follow its frequencies
         if (a.nbp <= 1) cnt = nullptr;
     }
-    expand_sweep<P, ONESB, INC, OUTC, false>(ix, sbl, parked, &tile_ctr, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax, nullptr);
+    expand_sweep<P, ONESB, INC, OUTC, false>(ix, sbl, parked, &tile_ctr, row_ring, a.rowctr + a.rowsel * LF_ROWCTRS, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax, nullptr);
 }
 
 template <typename P, bool ONESB, bool INC, bool OUTC>
@@ -618,6 +700,8 @@ void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
+    __shared__ unsigned long long row_ring[ROW_RING];
+    if (LF_DYNAMIC && blockIdx.x == 0 && threadIdx.x == 0) a.rowctr[(a.rowsel ^ 1u) * LF_ROWCTRS + blockIdx.y] = 0;
     const ExpandSample& S = b.s[blockIdx.y];
     a.sb = S.sb;
 #pragma unroll
@@ -625,7 +709,7 @@ void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters
     a.access_pack = S.access_pack;
     a.costsum_lo = S.costsum_lo;
     a.costsum_hi = S.costsum_hi;
-    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
+    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, row_ring, a.rowctr + a.rowsel * LF_ROWCTRS + blockIdx.y, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
 }
 
 // ---------------------------------------------------------------------------------------------
