@@ -621,12 +621,13 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
 // (4 x 64 bits per 64 parents); from them a client only needs the next level's links (4 * parent + symbol), from which its
 // LF-step kernel derives the handles of its own records (expand_tile, SELF).  Tile counts, one scan, links.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__ kplane, u32 nw, u32* __restrict__ cnt4, u32 nbp) {
+// (kshift: log2 of the words a wave's entry takes in kplane -- 2, or 3 for the whole lines a single sample's LF-step kernel writes)
+__global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__ kplane, u32 nw, u32* __restrict__ cnt4, u32 nbp, u32 kshift) {
     const u32 tile = blockIdx.x * 64 + (threadIdx.x >> 2), c = threadIdx.x & 3;  // one thread per (tile, symbol)
     if (tile >= nbp) return;
     u32 s = 0;
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) { const u32 w = tile * 4 + q; if (w < nw) s += (u32)__popcll(kplane[(size_t)w * 4 + c]); }
+    for (u32 q = 0; q < 4; ++q) { const u32 w = tile * 4 + q; if (w < nw) s += (u32)__popcll(kplane[((size_t)w << kshift) + c]); }
     cnt4[(size_t)c * nbp + tile] = s;
 }
 __global__ __launch_bounds__(256) void lite_slot_kernel(const u64* __restrict__ kplane, u32 F, const u32* __restrict__ cnt4, u32 nbp, u32 single_tile,
@@ -1890,8 +1891,6 @@ class Engine {
     u32 *cnt4 = nullptr, *scan_tmp = nullptr;  // [4][tiles] child counts of the level being advanced -> scanned offsets
     u32* cntraw = nullptr;                     // single sample: the counts as the expand kernel accumulates them (kept zero between levels)
     LfGeometry lfgeo{256, 16};                 // resident workgroups of the LF-step kernel and their waves (expand.hip)
-    u32* d_rowctr = nullptr;                   // the LF-step launches' row counters: two sets, used alternately (ExpandArgs::rowctr)
-    u32 lf_sel = 0;
     u16* sinfo = nullptr;
     u16* nT[2] = {nullptr, nullptr};
     u8* samechild = nullptr;
@@ -2087,8 +2086,6 @@ class Engine {
             DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
         }
         if (int rc = lf_step_geometry(sizeof(P) == 8, device, &lfgeo)) return rc;  // (all waves of an LF-step launch are resident)
-        if (int rc = dalloc(d_rowctr, (size_t)2 * LF_ROWCTRS)) return rc;
-        DSM_HIP(hipMemset(d_rowctr, 0, 2 * LF_ROWCTRS * sizeof(u32)));
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
         if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
@@ -2223,7 +2220,6 @@ class Engine {
         L.reserve(512);
         DSM_HIP(hipMemsetAsync(d_counters, 0, (size_t)COUNTER_SHARDS * 8 * sizeof(u64), st));
         if (cntraw) DSM_HIP(hipMemsetAsync(cntraw, 0, (4 * (size_t)(Seg / TILE) + 8) * sizeof(u32), st));  // a run that failed mid-level may have left counts
-        DSM_HIP(hipMemsetAsync(d_rowctr, 0, 2 * LF_ROWCTRS * sizeof(u32), st));
         DSM_HIP(hipEventRecord(ev0, st));
         size_t nev = 0;
 
@@ -2399,10 +2395,9 @@ class Engine {
                 // record formats: this level's records are compact iff its parent level was narrow (fmt_in), the children's iff this one is
                 if (self_mode) {  // several samples: one launch for up to BATCH_MAX of this process's
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;
-                    static const u32 grid_factor = getenv("DSM_BATCH_GRID_FACTOR") ? (u32)atoi(getenv("DSM_BATCH_GRID_FACTOR")) : 8u;
+                    static const u32 grid_factor = getenv("DSM_BATCH_GRID_FACTOR") ? (u32)atoi(getenv("DSM_BATCH_GRID_FACTOR")) : 1u;
                     lc.one_sb = all_one_sb;
-                    ea.rowctr = d_rowctr; ea.rowsel = lf_sel; lf_sel ^= 1u;
-                    lf_step_launch_batch(lc, lfgeo, grid_factor ? grid_factor : 8u, nb, st, eb, ea, d_counters, d_childmax);
+                    lf_step_launch_batch(lc, lfgeo, grid_factor ? grid_factor : 1u, nb, st, eb, ea, d_counters, d_childmax);
                     nb = 0;
                     ++stats.expand_launches;
                     continue;
@@ -2412,10 +2407,9 @@ class Engine {
                 for (int c = 0; c < 4; ++c) ea.cost[c] = es.cost[c];
                 ea.access_pack = es.access_pack; ea.costsum_lo = es.costsum_lo; ea.costsum_hi = es.costsum_hi;
                 lc.one_sb = (m.n >> SB_SHIFT) == 0;
-                u32* ecnt = (d == 1 && (ea.nbp > 1 || dynamic)) ? cntraw : (u32*)nullptr;
+                u32* ecnt = nullptr;  // (round 4: the tile counts of a single sample are counted from its planes by lite_count_kernel, not by atomics here)
                 // (a launch queued ahead: Fmax bounds the level -- four children per node of the level before it)
                 const u64 tiles_bound = dynamic ? (Fmax == ~0ull ? ~0ull >> 8 : (Fmax + 63) / 64) : ((u64)F + 63) / 64;
-                ea.rowctr = d_rowctr; ea.rowsel = lf_sel; lf_sel ^= 1u;
                 lf_step_launch(lc, lfgeo, tiles_bound, st, idx[s]->dev, rp[cur][s], rec[cur][s], rec[nxt][s], splane[s], ecnt, es.valf, es.pl, ea, d_counters,
                                d_childmax);
                 ++stats.expand_launches;
@@ -2467,7 +2461,7 @@ class Engine {
                     const u64* planes = reinterpret_cast<const u64*>(bc_buf + 16);
                     const u32 nbp = (F + TILE - 1) / TILE;
                     if (nbp > 1) {
-                        hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, planes, nwv, cnt4, nbp);
+                        hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, planes, nwv, cnt4, nbp, 2u);
                         exclusive_scan<u32, u32>(cnt4, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
                     }
                     hipLaunchKernelGGL(lite_slot_kernel, dim3(nbp), dim3(256), 0, st, planes, F, cnt4, nbp, nbp == 1 ? 1u : 0u, lite_slot[nxt], Fcap);
@@ -2564,8 +2558,10 @@ class Engine {
                 ao.kshift = 3;
             }
             if (nbp > 1) {
+                // one sample: the tile counts from the planes its LF-step kernel wrote (that kernel added them up with four atomics per
+                // tile of 64 nodes before: 470 K memory-side atomics per launch of the wide levels)
+                if (!merged) hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, splane[0], (F + 63) >> 6, cntraw, nbp, 3u);
                 exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
-                if (!merged) ao.cnt_clear = cntraw;
             }
             // ---- the output predicates for the nodes of THIS level (their children are known now) ride in the wave sweep; the scan of
             // the candidate counts is queued ahead of the wait ----

@@ -22,14 +22,14 @@ constexpr bool LF_DYNAMIC = false;   // round 3's distribution: 256-thread workg
 #else
 constexpr bool LF_DYNAMIC = true;
 #endif
-#ifndef DSM_LF_FIXED_PCT
-#define DSM_LF_FIXED_PCT 70
-#endif
-constexpr u32 LF_FIXED_SHARE_PCT = DSM_LF_FIXED_PCT;  // share of a level's rows that the workgroups take in a fixed pattern (see TileSeq)
 template <typename P>
 struct LfShape {
     static constexpr int WAVES_PER_SIMD = sizeof(P) == 4 ? 4 : 3;   // 128 / 168 vector registers
+#ifdef DSM_LF_WPB
+    static constexpr int WPB = DSM_LF_WPB;
+#else
     static constexpr int WPB = LF_DYNAMIC ? 4 * WAVES_PER_SIMD : 4;  // waves per workgroup
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -51,25 +51,25 @@ __device__ __forceinline__ void blk_counts4(const Blk16& r, u32 off, u32 out[4])
 
 // LF(c, x-1) for c = A,C,G,T at once: out[c] = C[c] + occurrences of c in BWT[0, x).
 template <typename P, bool ONESB>
-__device__ __forceinline__ void rank4_blk(const SbArgs& sa, const u64* sbl, const Blk16& r, u64 x, P out[4]) {
+__device__ __forceinline__ void rank4_blk(const SbArgs& sa, const u64* sbl, const Blk16& r, P x, P out[4]) {
     u32 c4[4];
     blk_counts4(r, (u32)(x & (BLK_SYMS - 1)), c4);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = (P)((ONESB ? sa.sb0[c] : sbl[(x >> SB_SHIFT) * 4 + c]) + r.cnt[c] + c4[c]);
+    for (int c = 0; c < 4; ++c) out[c] = (ONESB ? (P)sa.sb0[c] : (P)sbl[(size_t)((u64)x >> SB_SHIFT) * 4 + c]) + (P)(r.cnt[c] + c4[c]);
 }
 
 // LF(c, x-1) for one base chosen per lane (c = 0..3), on the plane words of a block; cntc = the block's count of that base.
 // A plane is taken as it is or inverted, so the base needs no branch.
 template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a, u64 p0b, u64 p1a, u64 p1b, u64 p2a, u64 p2b, u32 cntc, u64 x, u32 c) {
+__device__ __forceinline__ P rank_one(const SbArgs& sa, const u64* sbl, u64 p0a, u64 p0b, u64 p1a, u64 p1b, u64 p2a, u64 p2b, u32 cntc, P x, u32 c) {
     const u32 off = (u32)(x & (BLK_SYMS - 1));
     const u64 ma = off >= 64 ? ~0ull : ((1ull << off) - 1);
     const u64 mb = off > 64 ? ((1ull << (off - 64)) - 1) : 0ull;
     const u64 i0 = (c & 1u) ? 0ull : ~0ull, i1 = (c & 2u) ? 0ull : ~0ull;
     const u64 xa = ma & ~p2a & (p1a ^ i1) & (p0a ^ i0);
     const u64 xb = mb & ~p2b & (p1b ^ i1) & (p0b ^ i0);
-    const u64 base = ONESB ? DSM_PICK(sa.sb0, c) : sbl[(x >> SB_SHIFT) * 4 + c];
-    return (P)(base + cntc + (u32)(__popcll(xa) + __popcll(xb)));
+    const P base = ONESB ? (P)DSM_PICK(sa.sb0, c) : (P)sbl[(size_t)((u64)x >> SB_SHIFT) * 4 + c];
+    return base + (P)(cntc + (u32)(__popcll(xa) + __popcll(xb)));
 }
 
 // The index blocks of a tile are staged in LDS.  The intervals of a tile's nodes are disjoint and increase along the lanes, so
@@ -89,7 +89,7 @@ __device__ __forceinline__ void staged_blk(const uint4* wl, u32 idx, Blk16& r) {
     r.p2a = ((u64)d.y << 32) | d.x; r.p2b = ((u64)d.w << 32) | d.z;
 }
 template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 idx, u64 x, u32 c) {
+__device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const uint4* wl, u32 idx, P x, u32 c) {
     const uint4 q1 = wl[idx * 4 + 1], q2 = wl[idx * 4 + 2], q3 = wl[idx * 4 + 3];
     const u32 cntc = reinterpret_cast<const u32*>(wl + idx * 4)[c];
     return rank_one<P, ONESB>(sa, sbl, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z, ((u64)q2.y << 32) | q2.x, ((u64)q2.w << 32) | q2.z,
@@ -97,9 +97,9 @@ __device__ __forceinline__ P rank_staged(const SbArgs& sa, const u64* sbl, const
 }
 // the same from memory (positions outside the two blocks a lane holds: intervals over more than two blocks only)
 template <typename P, bool ONESB>
-__device__ __forceinline__ P rank_load(const DevIndex& ix, const SbArgs& sa, const u64* sbl, u64 x, u32 c) {
+__device__ __forceinline__ P rank_load(const DevIndex& ix, const SbArgs& sa, const u64* sbl, P x, u32 c) {
     Blk16 b;
-    load_blk(ix.blk, x >> BLK_SHIFT, b);
+    load_blk(ix.blk, (u64)(x >> BLK_SHIFT), b);
     return rank_one<P, ONESB>(sa, sbl, b.p0a, b.p0b, b.p1a, b.p1b, b.p2a, b.p2b, DSM_PICK(b.cnt, c), x, c);
 }
 
@@ -112,8 +112,12 @@ __device__ __forceinline__ u32 lf_bits_below_lane(u64 p) {  // set bits of p bel
     return __builtin_amdgcn_mbcnt_hi((u32)(p >> 32), __builtin_amdgcn_mbcnt_lo((u32)p, 0u));
 }
 
-__device__ __forceinline__ u32 costsum(const ExpandArgs& a, u32 set) {
-    return (u32)((set < 10 ? a.costsum_lo >> (6 * set) : a.costsum_hi >> (6 * (set - 10))) & 63u);
+// BitRank::rank calls per LF on A,C,G,T in the reference, four bits each (the argument block's cost[] in one scalar register), and
+// their sum over a set of bases
+__device__ __forceinline__ u32 cost_of(u32 cost_pack, u32 c) { return (cost_pack >> (4 * c)) & 15u; }
+__device__ __forceinline__ u32 costsum(u32 cost_pack, u32 set) {
+    return ((set & 1u) ? cost_pack & 15u : 0u) + ((set & 2u) ? (cost_pack >> 4) & 15u : 0u) + ((set & 4u) ? (cost_pack >> 8) & 15u : 0u) +
+           ((set & 8u) ? (cost_pack >> 12) & 15u : 0u);
 }
 // the set bits of a 4-bit mask in increasing order, two bits each (masks 0-7 in LO, 8-15 in HI, eight bits per mask)
 __device__ __forceinline__ u32 bit_list(u32 m) {
@@ -219,47 +223,38 @@ __device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32
     }
 }
 
-struct ExpandAcc {  // per-lane counters, reduced once at the end of the launch
-    // (k <= 4, live <= 1, lines <= 12, lf <= 40 per tile and lane: 16-bit halves hold thousands of tiles)
-    u32 kne = 0, ll = 0, lf = 0, rank = 0;
-    u32 rbytes = 0;     // bytes of records read and written
+// Counters of a wave's sweep.  They are sums over the lanes, and every term is a population count of a lane mask the tile computes
+// anyway (children per symbol, nodes with at least i left-extension intervals, ...): the sums are formed by the scalar unit, per wave,
+// and need neither vector registers nor a reduction at the end (round 4; per-lane accumulators before).
+struct ExpandAcc {
+    u32 kne = 0;        // children emitted (when they count as reported)
+    u32 live = 0;       // records read
+    u32 lines = 0;      // index blocks fetched
+    u32 lf = 0, rank = 0;  // what the reference would have spent: LF calls, BitRank::rank calls
+    u32 rbytes = 0;     // bytes of records read and written (wave-uniform part)
+    u32 rb_lane = 0;    // ... per lane: wide child records only, whose size depends on the intervals a child keeps
     u32 wide = 0;       // bit 0: some surviving child has a frequency of 512 or more, bit 1: of 65535 or more (the next level's column format)
 };
+__device__ __forceinline__ u32 mask_count(u64 m) { return (u32)__popcll(m); }
 
-// Which tile a wave takes next.
-// Dynamic, two levels.  (1) The workgroup's waves share a draw counter in LDS: draw k is slot k % WPB of the workgroup's local row
-// k / WPB, a row being WPB consecutive tiles.  (2) Which row of the level a local row j is: the first jstat rows of every
-// workgroup are fixed (row j * G + b, G = workgroups of the launch), the rest -- about the last third of the level -- are handed out
-// by a counter in global memory, so that the CUs that got through their fixed share early (the XCDs differ by 10-20 %, and a
-// level of a few rows per CU does not divide evenly) take more of it.  A draw from global memory takes microseconds: the wave that
-// draws slot 0 of local row j requests the row for j + 2 and publishes it, one tile later, in a ring in LDS that the draws of that
-// row read (and wait for, if they come early).  The counter belongs to the launch: launches alternate between two sets, and a
-// launch clears the set the next one will use.
-// Static (round 3): wave gw of nwaves takes gw, gw + nwaves, ...
-// A draw past the level's last tile means "no tile"; the draws of a wave increase, so every later one is past it too.
-constexpr u32 ROW_RING = 16;
+// Which tile a wave takes next.  Dynamic: the workgroup's waves share a counter in LDS; draw k of workgroup b is tile
+// ((k / WPB) * G + b) * WPB + k % WPB -- rows of WPB consecutive tiles, G rows apart (G = workgroups of the launch).  Static (round 3):
+// wave gw of nwaves takes gw, gw + nwaves, ...  A draw past the level's last tile means "no tile"; the draws of a wave increase, so
+// every later one is past it too.
+// (Measured and not kept: handing the rows out through a counter in global memory as well, so that the CUs that are done early take
+// more -- the CUs' ends then coincide, the launch does not get shorter (77.4-77.9 against 77.3-77.7 ms per pass), and the bookkeeping
+// costs registers the kernel does not have: profiles/r04_experiments.)
 template <int WPB>
 struct TileSeq {
-    u32* ctr;                   // dynamic: the workgroup's draw counter (LDS)
-    unsigned long long* ring;   // dynamic: [ROW_RING] local row << 32 | the global counter's answer for it (LDS)
-    u32* rowctr;                // dynamic: this launch's row counter (global)
-    u32 G, b;                   // workgroups of the launch, this one
-    u32 jstat;                  // local rows below this are fixed
-    u32 pend_j = ~0u, pend_v = 0;  // a row requested from the global counter and not yet published (pend_v: lane 0)
-    u32 last;                   // static: the tile drawn last
-    u32 stride;                 // static: waves of the launch
+    u32* ctr;     // dynamic: the workgroup's counter (LDS)
+    u32 G, b;     // workgroups of the launch, this one
+    u32 last;     // static: the tile drawn last
+    u32 stride;   // static: waves of the launch
     __device__ __forceinline__ u32 issue() {  // the draw is an LDS atomic: issued here, its value is taken by take()
         if (!LF_DYNAMIC) return 0u;
         u32 k = 0;
         if ((threadIdx.x & 63) == 0) k = atomicAdd(ctr, 1u);
         return k;
-    }
-    __device__ __forceinline__ void publish() {
-        if (pend_j != ~0u) {
-            if ((threadIdx.x & 63) == 0)
-                __hip_atomic_store(ring + (pend_j & (ROW_RING - 1)), ((unsigned long long)pend_j << 32) | pend_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pend_j = ~0u;
-        }
     }
     __device__ __forceinline__ u32 take(u32 issued) {
         if (!LF_DYNAMIC) {
@@ -268,25 +263,7 @@ struct TileSeq {
             return far;
         }
         const u32 k = (u32)__builtin_amdgcn_readfirstlane((int)issued);
-        const u32 j = k / (u32)WPB, s = k % (u32)WPB;
-        publish();  // (what this wave requested a tile ago; before it may wait for a row itself)
-        if (s == 0 && j + 2 >= jstat) {
-            if ((threadIdx.x & 63) == 0) pend_v = atomicAdd(rowctr, 1u);
-            pend_j = j + 2;
-        }
-        u32 row = j * G + b;
-        if (j >= jstat) {
-            unsigned long long e;
-            u32 spins = 0;
-            for (;;) {
-                e = __hip_atomic_load(ring + (j & (ROW_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((u32)(e >> 32) == j) break;
-                if (++spins > (1u << 24)) __builtin_trap();  // (a row that never arrives would hang the card: fail loudly instead)
-                __builtin_amdgcn_s_sleep(2);
-            }
-            row = jstat * G + (u32)__builtin_amdgcn_readfirstlane((int)(u32)e);
-        }
-        return row * (u32)WPB + s;
+        return ((k / (u32)WPB) * G + b) * (u32)WPB + k % (u32)WPB;
     }
     __device__ __forceinline__ u32 next() { return take(issue()); }
 };
@@ -314,7 +291,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                             u8* __restrict__ pl, const ExpandArgs& a, const u32 t, TileSeq<WPB>& seq, u32& tfar, const u32 ntile,
                                             const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
-                                            const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab) {
+                                            const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab, const u32 cost_pack) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
     const size_t cap = a.cap;
@@ -327,14 +304,13 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const u32 emask = nd.emask;
     const u32 ne = __popc(emask);
     u32 keepw = ~0u;  // the word of the keep table that holds this node's frequency (requested here, used at the candidate ballot)
-    const u64 freq1 = (u64)ep - (u64)sp + 1;
-    if (!SELF) keepw = keeptab[(freq1 < KEEP_FREQS ? (u32)freq1 : 0u) >> 5];
-    const u64 b0 = (u64)sp >> BLK_SHIFT, b1 = ((u64)ep + 1) >> BLK_SHIFT;  // blocks of the two interval ends
-    u32 n_lf = 0, n_rank = 0, lines = 0;
+    const P freq1 = ep - sp + 1;   // (positions stay of type P: no 64-bit arithmetic on a 32-bit index)
+    if (!SELF) keepw = keeptab[(freq1 < (P)KEEP_FREQS ? (u32)freq1 : 0u) >> 5];
+    const P ep1 = ep + 1;
+    const P b0 = sp >> BLK_SHIFT, b1 = ep1 >> BLK_SHIFT;  // blocks of the two interval ends
     P Rsp[4], Rep[4];
     u32 present = 0;  // bit c: child c is emitted
     u32 idx0, idx1;   // numbers of this lane's two blocks among the tile's distinct blocks
-    u32 rb_out = 0;   // bytes of child records this lane writes
     {
         // ---- the distinct blocks of the tile (see the staging note above) ----
         u32* list = reinterpret_cast<u32*>(wl + STAGE_BLOCKS * 4);
@@ -352,7 +328,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         idx0 = f0 ? before : (before ? before - 1u : 0u);
         idx1 = f1 ? idx0 + 1u : idx0;
         if (!live) { idx0 = 0; idx1 = 0; }
-        lines = (f0 ? 1u : 0u) + (f1 ? 1u : 0u);
+        acc.lines += D;
         if (f0) list[idx0] = (u32)b0;
         if (f1) list[idx1] = (u32)b1;
         if (D == 0 && lane == 0) list[0] = 0;
@@ -409,10 +385,10 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         // No branch on `live` around the ranks: an absent node holds the empty interval [1, 0], every child of which is empty.
         Blk16 r0;
         staged_blk(wl, idx0, r0);
-        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)sp, Rsp);  // LF(c, sp-1)
-        const u32 lcode = blk_code_at(r0, (u32)((u64)sp & (BLK_SYMS - 1)));  // BWT[sp], for the size-1 path
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, sp, Rsp);  // LF(c, sp-1)
+        const u32 lcode = blk_code_at(r0, (u32)sp & (BLK_SYMS - 1));  // BWT[sp], for the size-1 path
         staged_blk(wl, idx1, r0);
-        rank4_blk<P, ONESB>(a.sb, sbl, r0, (u64)ep + 1, Rep);  // LF(c, ep)
+        rank4_blk<P, ONESB>(a.sb, sbl, r0, ep1, Rep);  // LF(c, ep)
 #ifdef DSM_LF_SENS_VALU  // sensitivity probe: the two four-base ranks a second time (about 110 vector instructions per tile more)
         {
             u32 i0b = idx0, i1b = idx1;
@@ -420,44 +396,74 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             P R2[4], R3[4];
             Blk16 rr;
             staged_blk(wl, i0b, rr);
-            rank4_blk<P, ONESB>(a.sb, sbl, rr, (u64)sp, R2);
+            rank4_blk<P, ONESB>(a.sb, sbl, rr, sp, R2);
             staged_blk(wl, i1b, rr);
-            rank4_blk<P, ONESB>(a.sb, sbl, rr, (u64)ep + 1, R3);
+            rank4_blk<P, ONESB>(a.sb, sbl, rr, ep1, R3);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (R2[c] != Rsp[c] || R3[c] != Rep[c]) acc.wide |= 4u;
+            for (int c = 0; c < 4; ++c) if (__any(R2[c] != Rsp[c] || R3[c] != Rep[c])) acc.wide |= 4u;
         }
 #endif
 #if defined(DSM_LF_SENS_GATHER) || defined(DSM_LF_SENS_STREAM)
-        if ((sens0.x ^ sens1.y ^ sens2.z ^ sens3.w) == 0x9e3779b9u && sens0.w == 0x7f4a7c15u) acc.wide |= 4u;  // (never: the loads must stay)
+        if (__any((sens0.x ^ sens1.y ^ sens2.z ^ sens3.w) == 0x9e3779b9u && sens0.w == 0x7f4a7c15u)) acc.wide |= 4u;  // (never: the loads must stay)
 #endif
-        const bool single = (a.symbol_phase & 1u) && sp == ep;  // followOneBranch, EnumerateQuery.cpp:105-149
-        u32 nonempty = 0;  // bit c: the child interval of base c is non-empty
+        // ---- the children: child c of a node is the interval [Rsp[c], Rep[c] - 1], empty when the two ranks agree (an absent node
+        // holds the empty interval [1, 0]); it is emitted when its frequency reaches fmin (EnumerateQuery.cpp:186).  No branches:
+        // the comparisons ARE the wave's child masks.
+        u64 nemask[4];    // lanes whose child c is non-empty (what the reference pays left-extension ranks for)
+        P fmax = 0;       // largest frequency among this lane's emitted children
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if ((a.allowed >> c) & 1u) {
-                const P nsp = Rsp[c], nep = Rep[c] - 1;
-                if (nsp <= nep) {
-                    nonempty |= 1u << c;
-                    if ((u64)(nep - nsp) + 1 >= (u64)a.fmin) {  // EnumerateQuery.cpp:186
-                        present |= 1u << c;
-                        if ((u64)(nep - nsp) + 1 >= PACK_FMAX) acc.wide |= (u64)(nep - nsp) + 1 >= 65535 ? 3u : 1u;
-                    }
-                }
-            }
+            const P f = Rep[c] - Rsp[c];
+            const bool okc = ((a.allowed >> c) & 1u) != 0 && live;
+            const bool ne_c = okc && f != 0;
+            const bool pr_c = ne_c && f >= (P)a.fmin;
+            nemask[c] = __ballot(ne_c);
+            present |= pr_c ? (1u << c) : 0u;
+            fmax = pr_c && f > fmax ? f : fmax;
+        }
+        {
+            const u64 w1 = __ballot(fmax >= (P)PACK_FMAX), w2 = __ballot(fmax >= (P)65535);
+            acc.wide |= (w1 ? 1u : 0u) | (w2 ? 3u : 0u);
         }
         // What the reference would have spent on this node: two LF per attempted base (Query::pushChar, Query.h:37-45) and two per
         // left-extension interval for every base whose interval is non-empty; BitRank::rank calls = LF calls weighted by the
-        // base's code length (a.costsum: the sums per set of bases, six bits each).
-        n_lf = 2 * (u32)__popc(a.allowed) + 2 * ne * (u32)__popc(nonempty);
-        n_rank = 2 * costsum(a, a.allowed) + 2 * ne * costsum(a, nonempty);
-        if (__any(single)) {  // nodes of frequency 1 follow one branch by getL instead (only reachable with fmin = 1)
+        // base's code length.  Summed over the wave: (lanes with at least i intervals) x (lanes whose child c is non-empty), as masks.
+        const bool single = (a.symbol_phase & 1u) && sp == ep && live;  // followOneBranch, EnumerateQuery.cpp:105-149
+        if (!__any(single)) {
+            const u64 lv = __ballot(live);
+            const u64 m1 = __ballot(ne >= 1), m2 = __ballot(ne >= 2);
+            u32 s_lf = 0, s_rank = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 sc = mask_count(m1 & nemask[c]) + mask_count(m2 & nemask[c]);
+                s_lf += sc; s_rank += sc * cost_of(cost_pack, c);
+            }
+            if (__any(ne > 2)) {  // (well under one node in a hundred)
+                const u64 m3 = __ballot(ne >= 3), m4 = __ballot(ne >= 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32 sc = mask_count(m3 & nemask[c]) + mask_count(m4 & nemask[c]);
+                    s_lf += sc; s_rank += sc * cost_of(cost_pack, c);
+                }
+            }
+            const u32 nl = mask_count(lv);
+            acc.lf += 2u * ((u32)__popc(a.allowed) * nl + s_lf);
+            acc.rank += 2u * (costsum(cost_pack, a.allowed) * nl + s_rank);
+        } else {  // nodes of frequency 1 follow one branch by getL instead (only reachable with fmin = 1): per lane, then summed
+            u32 nonempty = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nonempty |= ((nemask[c] >> lane) & 1ull) ? (1u << c) : 0u;
+            u32 n_lf = 2 * (u32)__popc(a.allowed) + 2 * ne * (u32)__popc(nonempty);
+            u32 n_rank = 2 * costsum(cost_pack, a.allowed) + 2 * ne * costsum(cost_pack, nonempty);
             if (single) {
                 const bool go = a.allowed && ((nonempty >> lcode) & 1u) && lcode < 4;
                 n_lf = go ? 2 * ne + 2 : 0u;
-                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * DSM_PICK(a.cost, lcode) : 0u);
+                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * cost_of(cost_pack, lcode & 3u) : 0u);
             }
+            if (!live) { n_lf = 0; n_rank = 0; }
+            acc.lf += (u32)lf_wave_sum_u64(n_lf);
+            acc.rank += (u32)lf_wave_sum_u64(n_rank);
         }
-        if (!live) { n_lf = 0; n_rank = 0; present = 0; }
     }
     // ---- places of the child records: per symbol, rank of the parent inside the wave's tile ----
     const u32 k = __popc(present);
@@ -486,7 +492,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
     if (a.symbol_phase & 8u) {  // one sample: planes and the level's candidates in one line per tile (the advance sweep reads it)
         // metaserver.cpp:406-419 for a node with one reader: not a single child (416-417), no single left char (383-387, 418)
-        const bool ekeep = SELF || freq1 >= KEEP_FREQS || ((keepw >> ((u32)freq1 & 31u)) & 1u);  // the exact entropy verdict for this frequency
+        const bool ekeep = SELF || freq1 >= (P)KEEP_FREQS || ((keepw >> ((u32)freq1 & 31u)) & 1u);  // the exact entropy verdict for this frequency
         const u64 cb = __ballot(live && (a.symbol_phase & 4u) && k != 1u && !(mycode >= 1u && mycode <= 4u) && ekeep);
         if (lane < 6) {
             const u64 nc = (u64)__popcll(cb);
@@ -506,12 +512,10 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
         P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
         P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
-        rb_out = 0;
+        u32 j = 0, e = 0;  // the pair at hand: child j (in base order), interval e of the parent
 #pragma nounroll
         for (u32 p = 0; __any(p < npair); ++p) {
             const bool act = p < npair;
-            const u32 j = ne1 == 1 ? p : (ne1 == 2 ? p >> 1 : (ne1 == 4 ? p >> 2 : (p * 11u) >> 5));  // p / ne1 for p < 16
-            const u32 e = p - j * ne1;
             const u32 c = (cjpack >> (2 * j)) & 3u, kk = (kkpack >> (2 * e)) & 3u;
             const u32 q = DSM_PICK(qa, c);
             const P nsp = DSM_PICK(Rsp, c), nep1 = DSM_PICK(Rep, c);  // the child's interval is [nsp, nep1 - 1]
@@ -524,26 +528,28 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                     xmax = rec[(size_t)(3 + 2 * e) * cap + nd.r];
                 }
             }
-            const u64 xl = hasext ? (u64)xmin : (u64)sp, xh = hasext ? (u64)xmax + 1 : (u64)ep + 1;
+            const P xl = hasext ? xmin : sp, xh = hasext ? xmax + 1 : ep1;
             P l = nsp, h = nep1;
-            bool needl = xl != (u64)sp;
-            const bool needh = xh != (u64)ep + 1;
+            bool needl = xl != sp;
+            const bool needh = xh != ep1;
             if (e > 0 && xl == prevx) { l = prevh; needl = false; }  // adjacent intervals share an end: the rank is the previous pair's
             if (__any(needl)) {
                 if (needl) {
-                    const u64 bl = xl >> BLK_SHIFT;
+                    const P bl = xl >> BLK_SHIFT;
                     if (bl == b0 || bl == b1) l = rank_staged<P, ONESB>(a.sb, sbl, wl, bl != b0 ? idx1 : idx0, xl, c);
-                    else { l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c); ++lines; }
+                    else l = rank_load<P, ONESB>(ix, a.sb, sbl, xl, c);
                 }
+                acc.lines += mask_count(__ballot(needl && (xl >> BLK_SHIFT) != b0 && (xl >> BLK_SHIFT) != b1));
             }
             if (__any(needh)) {
                 if (needh) {
-                    const u64 bh = xh >> BLK_SHIFT;
+                    const P bh = xh >> BLK_SHIFT;
                     if (bh == b0 || bh == b1) h = rank_staged<P, ONESB>(a.sb, sbl, wl, bh != b0 ? idx1 : idx0, xh, c);
-                    else { h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c); ++lines; }
+                    else h = rank_load<P, ONESB>(ix, a.sb, sbl, xh, c);
                 }
+                acc.lines += mask_count(__ballot(needh && (xh >> BLK_SHIFT) != b0 && (xh >> BLK_SHIFT) != b1));
             }
-            prevx = (P)xh; prevh = h;
+            prevx = xh; prevh = h;
             if (hasext && l <= h - 1) {
                 if (cn == 0) { kl0 = l; kh0 = h - 1; }
                 else if (cn == 1) { kl1 = l; kh1 = h - 1; }
@@ -553,9 +559,12 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             }
             if (act && e == ne1 - 1) {
                 store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
-                rb_out += (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1) + (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P)) +
-                          (cn > 2 ? (cn - 2) * 2u * (u32)sizeof(P) : 0u);
+                // (bytes of the child's record beyond the compact word / the fixed fields: rare or wide levels only)
+                if (!OUTC) acc.rb_lane += (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P);
+                if (cn > 2) acc.rb_lane += (cn - 2) * 2u * (u32)sizeof(P);
             }
+            ++e;
+            if (e >= ne1) { e = 0; ++j; }
         }
     }
     if (i < a.F) {
@@ -568,17 +577,22 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             pl[i] = (u8)(present | (mycode << 4));
         }
     }
-    acc.kne += (a.symbol_phase & 2u) ? k : 0u; acc.ll += (live ? 1u : 0u) | (lines << 16); acc.lf += n_lf; acc.rank += n_rank;
-    // record bytes of this lane: its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3
-    // when in use) and its children's (compact word each, or their fields; rb_out collected by the rounds)
-    acc.rbytes += rb_out + (live ? (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + (ne > 2 ? (ne - 2) * 2u * (u32)sizeof(P) : 0u) : 0u);
+    {   // the wave's sums (scalar): children, records read, record bytes
+        const u32 nkids = mask_count(bal[0]) + mask_count(bal[1]) + mask_count(bal[2]) + mask_count(bal[3]);
+        const u32 nl = mask_count(__ballot(live));
+        acc.kne += (a.symbol_phase & 2u) ? nkids : 0u;
+        acc.live += nl;
+        // its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3 when in use) and its
+        // children's (compact word each, or their fixed fields; what depends on the kept intervals is in rb_lane)
+        acc.rbytes += nl * (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + nkids * (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1));
+        if (__any(ne > 2)) acc.rbytes += (mask_count(__ballot(ne > 2)) + mask_count(__ballot(ne > 3))) * 2u * (u32)sizeof(P);
+    }
 }
 
 // One sample's LF-step sweep over a level: the body of expand_kernel (one sample per launch) and of expand_batch_kernel.
 // tile_ctr: the workgroup's tile counter in LDS, zero when the sweep starts (the caller's barrier).
 template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF>
-__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, unsigned long long* row_ring, u32* rowctr,
-                                             const u32* __restrict__ rp, const P* __restrict__ rec,
+__device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, const u32* __restrict__ rp, const P* __restrict__ rec,
                                              P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                              u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
                                              unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane) {
@@ -589,23 +603,18 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         for (u32 q = threadIdx.x; q < nsb4 && q < SB_LDS_MAX * 4; q += blockDim.x) sbl[q] = ix.sbase[q];
     }
     if (LF_DYNAMIC && threadIdx.x == 0) *tile_ctr = 0;
-    if (LF_DYNAMIC && threadIdx.x < ROW_RING) row_ring[threadIdx.x] = ~0ull;
     if (!ONESB || LF_DYNAMIC) __syncthreads();
     const int lane = threadIdx.x & 63;
     const u32 gw = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6)));
     const u32 ntile = (a.F + 63) >> 6;
     const u32* keeptab = reinterpret_cast<const u32*>(counters + (size_t)COUNTER_SHARDS * 8);  // (see KEEP_FREQS)
     ExpandAcc acc;
+    const u32 cost_pack = (a.cost[0] & 15u) | ((a.cost[1] & 15u) << 4) | ((a.cost[2] & 15u) << 8) | ((a.cost[3] & 15u) << 12);
 #ifdef DSM_CLOCK_PROBE
     const u64 probe_c0 = __builtin_readcyclecounter(), probe_r0 = wall_clock64();
 #endif
     TileSeq<WPB> seq;
-    seq.ctr = tile_ctr; seq.ring = row_ring; seq.rowctr = rowctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
-    {   // the fixed share: 0.7 of the level's rows, and the rows the prologue draws in any case
-        const u32 rows = (ntile + (u32)WPB - 1) / (u32)WPB;
-        const u32 js = (u32)(((u64)rows * LF_FIXED_SHARE_PCT / 100u) / gridDim.x);
-        seq.jstat = js < 3u ? 3u : js;
-    }
+    seq.ctr = tile_ctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
     u32 tA, tB, tC = ~0u;
     if (LF_DYNAMIC) { tA = seq.next(); tB = seq.next(); if (SELF) tC = seq.next(); }
     else {
@@ -635,15 +644,14 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
         // t0 / t1 / t2: the wave's current tile and the ones whose heads / slots are on their way (t2: SELF only).
         u32 t0 = tA, t1 = tB, t2 = tC, tf = ~0u;
         while (t0 < ntile) {
-            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hA, hB, rn, acc, pplane, &ss, keeptab);
+            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hA, hB, rn, acc, pplane, &ss, keeptab, cost_pack);
             t0 = t1;
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
             if (t0 >= ntile) break;
-            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hB, hA, rn, acc, pplane, &ss, keeptab);
+            expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hB, hA, rn, acc, pplane, &ss, keeptab, cost_pack);
             t0 = t1;
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
         }
-        seq.publish();  // (a row this wave still owes the others)
     }
 #ifdef DSM_CLOCK_PROBE
     if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
@@ -659,13 +667,12 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
     }
 #endif
     // ---- counters (exact; the block lines include the ones the ext pass fetched): one reduction per wave and launch ----
-    if (__any(acc.wide != 0) && lane == 0) atomicMax(childmax, __any((acc.wide & 2u) != 0) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
+    if ((acc.wide & 3u) != 0 && lane == 0) atomicMax(childmax, (acc.wide & 2u) ? 65535ull : (unsigned long long)PACK_FMAX);  // only the class matters
     {
-        u64 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.ll >> 16, acc.rbytes, acc.ll & 0xFFFFu};
-#pragma unroll
-        for (int q = 0; q < NCOUNTERS; ++q) v[q] = lf_wave_sum_u64(v[q]);
+        const u32 extra_bytes = (u32)lf_wave_sum_u64(acc.rb_lane);  // (record bytes that depend on the intervals a lane's children kept: rare)
+        const u32 v[NCOUNTERS] = {acc.kne, acc.lf, acc.rank, acc.lines, acc.rbytes + extra_bytes, acc.live};
         if (lane < NCOUNTERS) {
-            u64 mine = v[0];
+            u32 mine = v[0];
 #pragma unroll
             for (int q = 1; q < NCOUNTERS; ++q) mine = lane == q ? v[q] : mine;
             if (mine) atomicAdd((unsigned long long*)&counters[(size_t)(gw & (COUNTER_SHARDS - 1)) * 8 + lane], (unsigned long long)mine);
@@ -681,8 +688,6 @@ void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict_
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
-    __shared__ unsigned long long row_ring[ROW_RING];
-    if (LF_DYNAMIC && blockIdx.x == 0 && threadIdx.x == 0) a.rowctr[(a.rowsel ^ 1u) * LF_ROWCTRS] = 0;  // the next launch's counter (also by a launch that finds nothing to do)
     if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
         const u32 F = a.dyn[0], cls = a.dyn[1];
         if ((cls & a.dyn_mask) != a.dyn_expect || F > a.fcap || F == 0) return;
@@ -691,7 +696,7 @@ void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict_
         if (a.w16 != 2) pl = reinterpret_cast<u8*>(valf) + (size_t)F * (a.w16 ? 2u : (u32)sizeof(P));  // one sample: the flag bytes follow its frequencies
         if (a.nbp <= 1) cnt = nullptr;
     }
-    expand_sweep<P, ONESB, INC, OUTC, false>(ix, sbl, parked, &tile_ctr, row_ring, a.rowctr + a.rowsel * LF_ROWCTRS, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax, nullptr);
+    expand_sweep<P, ONESB, INC, OUTC, false>(ix, sbl, parked, &tile_ctr, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax, nullptr);
 }
 
 template <typename P, bool ONESB, bool INC, bool OUTC>
@@ -700,8 +705,6 @@ void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
     __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
-    __shared__ unsigned long long row_ring[ROW_RING];
-    if (LF_DYNAMIC && blockIdx.x == 0 && threadIdx.x == 0) a.rowctr[(a.rowsel ^ 1u) * LF_ROWCTRS + blockIdx.y] = 0;
     const ExpandSample& S = b.s[blockIdx.y];
     a.sb = S.sb;
 #pragma unroll
@@ -709,7 +712,7 @@ void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters
     a.access_pack = S.access_pack;
     a.costsum_lo = S.costsum_lo;
     a.costsum_hi = S.costsum_hi;
-    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, row_ring, a.rowctr + a.rowsel * LF_ROWCTRS + blockIdx.y, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
+    expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -766,8 +769,10 @@ void lf_step_launch(const LfConfig& c, const LfGeometry& g, u64 tiles_bound, hip
 
 void lf_step_launch_batch(const LfConfig& c, const LfGeometry& g, u32 grid_factor, int nb, hipStream_t st, const ExpandBatch& b, const ExpandArgs& a, u64* counters,
                           unsigned long long* childmax) {
-    // (measured with eight samples and round 3's workgroups of four waves: 2 x resident -> 1255, 4 x -> 1219, 8 x -> 1189, 16 x -> 1184, 32 x -> 1198 ms per
-    // pass: the samples' sweeps finish unevenly, shorter strides even them out)
+    // The samples of the launch share the card: grid_factor x (resident workgroups / samples) workgroups each.  Measured with eight
+    // full-size samples and whole-CU workgroups: factor 1 -> 878, 2 -> 893, 4 -> 903, 8 -> 940 ms of LF-step sweeps per pass (every further
+    // workgroup is another start-up, and a workgroup's waves balance their tiles among themselves anyway); round 3's workgroups of four
+    // waves wanted 8 (972 ms).
     const u32 ntile = (a.F + 63) >> 6;
     u32 need = (ntile + g.waves_per_block - 1) / g.waves_per_block;
     if (need < 1) need = 1;

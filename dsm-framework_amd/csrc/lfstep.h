@@ -85,12 +85,7 @@ struct ExpandArgs {
     const u32* dyn;    // null: F, nbp and the formats above are final
     u32 dyn_expect, dyn_mask, fcap;
     u32 probe_slot;    // DSM_CLOCK_PROBE builds: counter shard that collects this launch's wave times
-    // Row counters of the launch (expand.hip, TileSeq): two sets of LF_ROWCTRS words, one word per sample of a batched launch;
-    // this launch draws from set rowsel and clears the other one for the launch that follows it on the stream.
-    u32* rowctr;
-    u32 rowsel;
 };
-constexpr u32 LF_ROWCTRS = 8;  // = BATCH_MAX
 
 // Several samples of one process in one launch: blockIdx.y picks the sample (its index, record buffers, columns and code costs come
 // from the batch block), so a level's launches are not eight short ones with eight tails but one wide one.
