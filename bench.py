@@ -253,6 +253,26 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
             x.close()
     except Exception as e:  # noqa: BLE001
         out.append({"record": "8 samples on one GPU", "error": repr(e)})
+    try:  # BASELINE configs[4] at its real d: 64 read sets resident on the one card, -P 1 --pmax 1 (sample-specific substrings).  A tenth of
+        # the default sample size, so that the 64 index builds keep the default run within minutes (the files
+        # tests/test_many_samples_gpu.py builds: shared through DSM_BENCH_DIR)
+        a64 = argparse.Namespace(**vars(args))
+        a64.gpus, a64.nlocal = 1, 64
+        a64.reads, a64.genome = max(1000, args.reads // 10), max(5000, args.genome // 10)
+        t0 = time.time()
+        paths = [build_index(a64, j, dev)[0] for j in range(64)]
+        build_s = time.time() - t0
+        ixs = [pydsm.Index(pth, device=local) for pth in paths]
+        for pm, px, lab in ((1, 1, "configs[4]: sample-specific substrings"), (2, 0, "the reference's default filter: reader-set orders past 13 samples")):
+            rec = one(ixs, "64 read sets of %d x %d bp (n=%d each) resident on one GPU, d=64, pmin=%d pmax=%d: %s" % (a64.reads, args.rlen, ixs[0].n, pm, px, lab),
+                      pmin=pm, pmax=px)
+            rec.update(dtype="u32", index_build_s=build_s, index_hbm_bytes=sum(x.device_bytes() for x in ixs))
+            out.append(rec)
+        for x in ixs:
+            x.close()
+    except Exception as e:  # noqa: BLE001
+        out.append({"record": "64 samples on one GPU (configs[4])", "error": repr(e)})
+    note("64 samples done")
     try:  # BASELINE configs[3]: 4-Gbase read sets (n = 8.08e9 > 2^32, real BWTs built here by dsm_bwt_build), first one alone, then
         # its one-card share: EIGHT of them resident (8 x 4 GB of index), d = 8, -P 2 --pmax 8
         from pydsm import builder

@@ -95,7 +95,7 @@ constexpr int NPT = 4;
 static inline dim3 grid_npt(u64 n) { return dim3((unsigned)((n + 256ull * NPT - 1) / (256ull * NPT))); }
 
 
-constexpr u32 BC_OK = 0x4f4b4f4bu, BC_CAPACITY = 0x46554c4cu;  // first word of the owner's broadcast: go on / split this prefix
+constexpr u32 BC_OK = 0x4f4b4f4bu, BC_CAPACITY = 0x46554c4cu, BC_ABORT = 0x41424f52u;  // first word of the owner's broadcast: go on / split this prefix / the owner failed
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
 // Several engines of one process (prefix lanes on their own streams) share the device.  Their expand launches are chained:
 // each waits for the previously issued expand of the process on that device, so two LF-step kernels never run side by
@@ -2203,6 +2203,27 @@ class Engine {
         std::vector<u32> sym;               // capture: symbol of each node at `depth`
         std::vector<std::vector<u16>> ord;  // capture: their orders; seed: ord[0]
     };
+    // Owner mode: between a level's gather and the broadcast that answers it the clients of the prefix wait for the owner.  Whatever
+    // makes the owner leave in between (a failed call, a sink error, a limit) must still answer, or the clients would wait for ever:
+    // the guard broadcasts BC_ABORT -- the same message size as the answer that was due -- when it goes out of scope armed.
+    // (A CLIENT that fails outside this path cannot tell the owner: its host must tear the communicator or the process down, see dsmhip.h.)
+    struct BcastGuard {
+        Engine* e;
+        size_t gather_bytes = 0;  // the clients have sent (or will send) their columns of the next level: take them first
+        void* gather_into = nullptr;
+        size_t bytes = 0;         // the broadcast they wait for; 0: nothing owed
+        explicit BcastGuard(Engine* e_) : e(e_) {}
+        void arm(size_t b) { gather_bytes = 0; bytes = b; }
+        void arm_next(size_t g, void* into, size_t b) { gather_bytes = g; gather_into = into; bytes = b; }
+        void disarm() { gather_bytes = 0; bytes = 0; }
+        ~BcastGuard() {
+            if (!bytes) return;
+            if (gather_bytes) (void)e->prm.gather(e->prm.owner_ctx, e->owner, e->xsend, gather_into, gather_bytes, (void*)e->st);
+            const u32 hdr[4] = {BC_ABORT, 0, 0, 0};
+            if (hipMemcpyAsync(e->bc_buf, hdr, 16, hipMemcpyHostToDevice, e->st) == hipSuccess) (void)hipStreamSynchronize(e->st);
+            (void)e->prm.bcast(e->prm.owner_ctx, e->owner, e->bc_buf, bytes, (void*)e->st);
+        }
+    };
     int run(const char* prefix_c, dsm_tuple_sink tsink, dsm_byte_sink bsink, void* ctx, bool emit = true, u32 emit_lo = 1,
             u32 emit_hi = ~0u, u32 expand_cap = ~0u, const NodeOrder* seed = nullptr, NodeOrder* capture = nullptr, bool count = true) {
         const std::string prefix = prefix_c ? prefix_c : "";
@@ -2423,6 +2444,8 @@ class Engine {
         DSM_HIP(hipMemsetAsync(multi ? xsend : xrecv[xcur], 0, XHDR, st));  // later levels: cleared by publish_kernel
         if (int rc = launch_expand(F, depth, cur, xcur, w16, w9, L[0].slot, fmt_in, false)) return rc;
         fmt_in = w16 && !trie_mode;  // the next level's records are compact iff this level is narrow
+        BcastGuard owed(this);  // (owner mode, on the owner: the answer to the level's gather, or the final verdict, is still due)
+        static const int test_owner_fail = getenv("DSM_TEST_OWNER_FAIL") ? atoi(getenv("DSM_TEST_OWNER_FAIL")) : -1;  // test hook: the owner fails at this depth
         while (true) {
             const u64 slots = (u64)F * 4;
             const u32 fb = w9 ? 1u : (w16 ? 2u : (u32)sizeof(P));
@@ -2438,6 +2461,7 @@ class Engine {
             const u32 nwv = (F + 63) >> 6;
             const size_t bc_bytes = 16 + (size_t)nwv * 32;
             if (owner_mode) {
+                owed.disarm();  // (the gather that was owed is this one; if it fails the communicator is gone and nobody can be told)
                 if (prm.gather(prm.owner_ctx, owner, xsend, xrecv[xcur], (size_t)bpr, (void*)st)) return fail(DSM_E_SINK, "gather callback failed");
                 if (!is_owner) {
                     // ---- a client of this prefix: wait for the owner's verdict on the level, then only the links of the next one ----
@@ -2448,6 +2472,7 @@ class Engine {
                     DSM_HIP(hipMemcpyAsync(hdr, bc_buf, 16, hipMemcpyDeviceToHost, st));
                     DSM_HIP(hipStreamSynchronize(st));
                     if (hdr[0] == BC_CAPACITY) return fail(DSM_E_CAPACITY, "the prefix does not fit the owner's device arena: use a longer prefix or a larger arena_bytes");
+                    if (hdr[0] == BC_ABORT) return fail(DSM_E_SINK, "the prefix's owner failed and aborted the prefix (its own error says why)");
                     if (hdr[0] != BC_OK) return fail(DSM_E_HIP, "malformed broadcast from the prefix's owner");
                     const u32 Fn = hdr[1] & 0x3FFFFFFFu;
                     w16 = !(hdr[1] >> 31);
@@ -2483,6 +2508,8 @@ class Engine {
                     continue;
                 }
                 stats.exchange_bytes_received += bpr * (u64)(world - 1);
+                owed.arm(bc_bytes);  // from here to the broadcast below every way out answers the clients (BC_ABORT)
+                if (test_owner_fail >= 0 && (int)depth == test_owner_fail) return fail(DSM_E_SINK, "injected owner failure (DSM_TEST_OWNER_FAIL)");
                 // the owner: whatever this level may allocate must fit before anything is sent back -- a failure later would leave the
                 // clients waiting.  (Emission-side allocations only flag a failure, see emit_failed.)
                 const size_t wc = (size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap;
@@ -2491,6 +2518,7 @@ class Engine {
                     const u32 hdr[4] = {BC_CAPACITY, 0, 0, 0};
                     DSM_HIP(hipMemcpyAsync(bc_buf, hdr, 16, hipMemcpyHostToDevice, st));
                     DSM_HIP(hipStreamSynchronize(st));
+                    owed.disarm();
                     if (prm.bcast(prm.owner_ctx, owner, bc_buf, bc_bytes, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
                     return fail(DSM_E_CAPACITY, "device arena exhausted: use a longer prefix or a larger arena_bytes");
                 }
@@ -2590,6 +2618,7 @@ class Engine {
             }
             if (owner_mode) {  // the union's child planes of this level follow the header: what a client needs to go on
                 DSM_HIP(hipMemcpyAsync(bc_buf + 16, me.kplane, (size_t)nwv * 32, hipMemcpyDeviceToDevice, st));
+                owed.disarm();
                 if (prm.bcast(prm.owner_ctx, owner, bc_buf, bc_bytes, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
                 stats.exchange_bytes_sent += bc_bytes * (u64)(world - 1);
             }
@@ -2621,7 +2650,11 @@ class Engine {
             const bool spec_hit = spec && Fn > 0 && Fn <= Fcap && w16 == spec_w16 && (!pack_columns || ((pk[1] >> 30) & 1u) == (spec_w9 ? 0u : 1u));
             if (spec && !spec_hit) --stats.expand_launches;  // (the launch queued ahead found no level, or another class, and did nothing)
             h_totals[300] = pk[2]; h_totals[301] = pk[3];  // candidate totals of this level (read by emit_store)
-            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");  // (the clients read the same width and stop too)
+            if (owner_mode) {  // what the clients do next: send the next level's columns and wait for its answer, or wait for the final verdict
+                if (!Fn) owed.arm(16);
+                else owed.arm_next((size_t)((((u64)nlocal * Fn * (w9 ? 2u : (w16 ? 3u : (u32)sizeof(P) + 1)) + 15) & ~15ull) + 16), xrecv[xcur ^ 1], 16 + (size_t)((Fn + 63) >> 6) * 32);
+            }
             // commit the provisional window at its real size
             arena.off = mark2;
             child.n = Fn;
@@ -2722,11 +2755,13 @@ class Engine {
                     DSM_HIP(hipMemcpyAsync(bc_buf, hdr, 16, hipMemcpyHostToDevice, st));
                     DSM_HIP(hipStreamSynchronize(st));
                 }
+                owed.disarm();
                 if (prm.bcast(prm.owner_ctx, owner, bc_buf, 16, (void*)st)) return fail(DSM_E_SINK, "bcast callback failed");
                 if (!is_owner) {
                     DSM_HIP(hipMemcpyAsync(hdr, bc_buf, 16, hipMemcpyDeviceToHost, st));
                     DSM_HIP(hipStreamSynchronize(st));
                 }
+                if (hdr[0] == BC_ABORT) return fail(DSM_E_SINK, "the prefix's owner failed and aborted the prefix (its own error says why)");
                 if (hdr[0] != BC_OK) return fail(DSM_E_CAPACITY, "device arena exhausted on the prefix's owner: use a longer prefix or a larger arena_bytes");
             } else if (multi) {  // every rank learns whether some rank's emission side overflowed: split together or not at all
                 u64 ok = emit_failed ? 0 : 1, all_ok = 0;
@@ -3600,7 +3635,7 @@ struct dsm_server {
     int rc = 0;
     std::string err;
     dsm_stats stats;
-    dsm::u64 units_merged = 0, peak_unit_nodes = 0;
+    std::atomic<dsm::u64> units_merged{0}, peak_unit_nodes{0};  // (written by the merger thread, read by dsm_server_units)
 
     ~dsm_server() {
         { std::lock_guard<std::mutex> lk(mu); quit = true; }
@@ -3985,7 +4020,12 @@ int dsm_server_feed(dsm_server* sv, int sample, const uint8_t* bytes, size_t n) 
         rc = st.sp.feed(bytes, n, false);
         if (!rc) { DSM_HIP(hipSetDevice(sv->device)); rc = sv->upload(st, false); }
     }
-    { std::lock_guard<std::mutex> lk(sv->mu); }  // (the merger is either before its look at the streams or already waiting)
+    {   // (the merger is either before its look at the streams or already waiting.)  A stream that cannot be parsed fails the whole
+        // server: the merger stops, the other connections' feeds and finish() return this error instead of waiting for an end that
+        // will not come.
+        std::lock_guard<std::mutex> lk(sv->mu);
+        if (rc && !sv->rc) { sv->rc = rc; sv->err = dsm_last_error(); }
+    }
     sv->cv.notify_all();
     return rc;
 }
@@ -4029,8 +4069,8 @@ int dsm_server_finish(dsm_server* sv, dsm_stats* stats) {
 }
 uint64_t dsm_server_units(const dsm_server* sv, uint64_t* peak_unit_nodes) {
     if (!sv) return 0;
-    if (peak_unit_nodes) *peak_unit_nodes = sv->peak_unit_nodes;
-    return sv->units_merged;
+    if (peak_unit_nodes) *peak_unit_nodes = sv->peak_unit_nodes.load();
+    return sv->units_merged.load();
 }
 void dsm_server_destroy(dsm_server* sv) { delete sv; }
 

@@ -54,7 +54,9 @@ struct StreamParser {
     std::vector<u8> open_path;       // symbols of the open nodes of those depths
     std::vector<int> last_closed;    // last_closed[k]: symbol of the last child closed under the open node of depth chain_len + k (-1: none)
     // can the stream still produce the event with this path?  (false once it is past it; the caller adds "or the stream has ended")
+    bool chain_done = false;         // the node at the end of the enforced path has closed: nothing below the path can come any more
     bool may_produce(const std::vector<u8>& ev) const {
+        if (chain_done) return false;                    // climbed back above the enforced path: its subtree is complete
         if (stack.size() - 1 < chain_len) return true;   // still on its way down the enforced path (or not started)
         const size_t m = open_path.size(), n = ev.size();
         const size_t c = m < n ? m : n;
@@ -185,6 +187,7 @@ private:
                     last_closed[open_path.size() - 1] = (int)open_path.back();
                     open_path.pop_back();
                 }
+                if (unit_depth && depth == chain_len) chain_done = true;  // (chain_len == 0: the root never closes, the stream's end says so)
                 stack.pop_back();
             }
         }

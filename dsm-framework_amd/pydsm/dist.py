@@ -145,13 +145,19 @@ class Exchange:
         self.calls += 1
 
     def gather(self, root, send_ptr, recv_ptr, nbytes, stream=None):
-        """recv[half][r * nbytes : (r+1) * nbytes] on rank `root` = rank r's send[:nbytes]; the others only send."""
+        """recv[half][r * nbytes : (r+1) * nbytes] on rank `root` = rank r's send[:nbytes]; the others only send.
+        `stream`: the HIP stream the library's kernels that wrote `send` run on; the transfers are ordered on it."""
+        self._lib_stream = stream
         if send_ptr != self.send.data_ptr():
             raise ValueError("send pointer is not the exchange send buffer")
         if nbytes > self.nbytes:
             raise ValueError("level larger than the exchange buffers")
         off = self.half(recv_ptr)
         self._turn(lambda: self._gather(root, nbytes, off))
+
+    def _global(self, r):
+        """torch.distributed's point-to-point and rooted calls take GLOBAL ranks, the library speaks in ranks of this exchange's group"""
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def _gather(self, root, nbytes, off):
         me = dist.get_rank(self.group)
@@ -161,13 +167,15 @@ class Exchange:
             out.copy_(src)
             return
         st = self.stream if self.stream is not None else (torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None)
+        if self.stream is None and self.device.type == "cuda" and getattr(self, "_lib_stream", None):
+            st = torch.cuda.ExternalStream(int(self._lib_stream), device=self.device)  # (the library's stream, not torch's current one)
         if self.backend == "nccl":
             with torch.cuda.stream(st):
                 if me == root:
                     out[root * nbytes:(root + 1) * nbytes].copy_(src)
-                    ops = [dist.P2POp(dist.irecv, out[r * nbytes:(r + 1) * nbytes], r, self.group) for r in range(self.world) if r != root]
+                    ops = [dist.P2POp(dist.irecv, out[r * nbytes:(r + 1) * nbytes], self._global(r), self.group) for r in range(self.world) if r != root]
                 else:
-                    ops = [dist.P2POp(dist.isend, src, root, self.group)]
+                    ops = [dist.P2POp(dist.isend, src, self._global(root), self.group)]
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
             self.bytes_moved += nbytes * (self.world - 1 if me == root else 1)
@@ -178,12 +186,12 @@ class Exchange:
         h_src = src.cpu()
         if me == root:
             parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
-            dist.gather(h_src, parts, dst=root, group=self.group)
+            dist.gather(h_src, parts, dst=self._global(root), group=self.group)
             out.copy_(torch.cat(parts))
             if st is not None:
                 st.synchronize()
         else:
-            dist.gather(h_src, None, dst=root, group=self.group)
+            dist.gather(h_src, None, dst=self._global(root), group=self.group)
         self.bytes_moved += nbytes * (self.world - 1 if me == root else 1)
 
     def bcast(self, root, ptr, nbytes, stream=None):
@@ -203,10 +211,10 @@ class Exchange:
             raise RuntimeError("dsm_copy_from_device failed")
         if self.backend == "nccl":
             d = h.to(self.device)
-            dist.broadcast(d, src=root, group=self.group)
+            dist.broadcast(d, src=self._global(root), group=self.group)
             h = d.cpu()
         else:
-            dist.broadcast(h, src=root, group=self.group)
+            dist.broadcast(h, src=self._global(root), group=self.group)
         if me != root and lib().dsm_copy_to_device(ptr, h.data_ptr(), nbytes, stream):
             raise RuntimeError("dsm_copy_to_device failed")
         self.bytes_moved += nbytes

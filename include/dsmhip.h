@@ -191,7 +191,13 @@ void dsm_rccl_gate_destroy(dsm_rccl_gate* g);
  *   gather: rank root must end up with world_size * bytes_per_rank bytes at recvbuf, rank-major, its own part included (sendbuf
  *           on root is its own contribution); the other ranks only send.
  *   bcast:  bytes at buf on root reach buf on every rank.
- * Device pointers, ordered on `stream` like dsm_allgather_fn. */
+ * Device pointers, ordered on `stream` like dsm_allgather_fn.
+ * Failures.  An owner that has to give a prefix up after it has taken a level's columns -- a failed call, a sink that refuses, a
+ * limit -- still answers: its next broadcast starts with an abort word, every client of the prefix returns DSM_E_SINK ("the prefix's
+ * owner failed"), the owner returns its own error; an arena that is too small is announced the same way and makes every rank split the
+ * prefix (DSM_E_CAPACITY inside, invisible outside).  A CLIENT that fails between two levels cannot tell the owner, which then waits
+ * in its gather: the host of a rank whose dsm_miner_* call returned an error other than DSM_E_CAPACITY in owner mode must tear down the
+ * communicator (or the process), as with any collective library. */
 typedef int (*dsm_gather_fn)(void* ctx, int root, const void* sendbuf, void* recvbuf, size_t bytes_per_rank, void* stream);
 typedef int (*dsm_bcast_fn)(void* ctx, int root, void* buf, size_t bytes, void* stream);
 /* the same over RCCL (ncclSend / ncclRecv in one group; ncclBroadcast), ctx = the dsm_rccl* */

@@ -190,6 +190,8 @@ def _owner_worker(rank, world, port, q, fmis, prefixes, kw, arena):
         t.join(240)
     q.put((rank, res, errs))
     if errs:
+        q.close()
+        q.join_thread()  # (the queue's feeder thread must have written the result before the process goes)
         os._exit(1)  # (the other ranks may be blocked in a collective)
     for st, ex, m in lanes:
         m.close()
@@ -241,6 +243,40 @@ def test_owner_mode_one_server_per_prefix(golden, setname, world, cfg, arena):
     assert all(len(v) == 1 for v in splits.values())  # owner and clients split the same prefixes
     if arena:
         assert sum(next(iter(v)) for v in splits.values()) > 0, "the small budget was meant to force prefix splits"
+
+
+def _owner_abort_worker(rank, world, port, q, fmis, prefixes, kw, fail_depth):
+    os.environ["DSM_TEST_OWNER_FAIL"] = str(fail_depth)  # the library's test hook: the owner of a prefix gives up at this depth, after the gather
+    _owner_worker(rank, world, port, q, fmis, prefixes, kw, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_depth", [0, 3])
+def test_owner_failure_reaches_every_rank(golden, fail_depth):
+    """an owner that fails between a level's gather and its broadcast must not leave the clients waiting.  Every owner is
+    made to fail (DSM_TEST_OWNER_FAIL) at a level after it has taken the columns: all three ranks come back, the owners with the
+    injected error, the clients with "the prefix's owner failed" -- nobody hangs in a collective."""
+    from goldenlib import server_args_to_kw
+    m = golden.manifest["sets"]["toy3"]
+    fmis = [golden.fmi("toy3", n) for n in m["names"]]
+    kw = server_args_to_kw(m["server_cfgs"]["default"])
+    kw["fmin"] = m["fmin"]
+    prefixes = ["A", "C", "G"]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_owner_abort_worker, args=(r, world, port, q, fmis, prefixes, kw, fail_depth)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)  # (a hang shows as a timeout here)
+    for p in ps:
+        p.join(60)
+    assert len(res) == world
+    for rank, lanes, errs in res:
+        assert len(errs) == world, (rank, errs)  # its own lane (owner) and the two lanes it is a client of
+        assert sum("injected owner failure" in e for e in errs) == 1, errs
+        assert sum("owner failed" in e for e in errs) == world - 1, errs
 
 
 def test_turn_gate_interleaves_lanes_deterministically():
