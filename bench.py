@@ -80,6 +80,18 @@ def build_index(args, rank, dev):
     return path, time.time() - t0
 
 
+def lf_kernel_sha():
+    """first 16 hex digits of the sha256 of the LF-step kernel's sources: ties profiles/traffic.json to the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("expand.hip", "lfstep.h", "common.h"):
+        try:
+            h.update(open(os.path.join(ROOT, "dsm-framework_amd", "csrc", f), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def host_cores():
     """CPU share of this job: affinity mask, capped by the cgroup quota when there is one."""
     n = len(os.sched_getaffinity(0))
@@ -650,11 +662,13 @@ def main():
         ref_equiv = tot["rank_ops"] * ALG_BYTES_PER_RANK / esec / 1e9 if esec > 0 else 0.0
         traffic, tinfo = None, {}
         tj = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 --pmc (see profiles/README)
+        kernel_sha = lf_kernel_sha()
         if os.path.exists(tj):
             try:
                 tinfo = json.load(open(tj))
+                # the offline counters describe ONE build of the kernel: they are quoted only next to the source they were taken from
                 if (tinfo.get("reads") == args.reads and tinfo.get("prefix_len") == plen and tinfo.get("gpus") == args.gpus and args.nlocal == 1
-                        and not args.wide and not args.stream_mode):
+                        and not args.wide and not args.stream_mode and tinfo.get("kernel_sha16") == kernel_sha):
                     traffic = tinfo.get("bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
@@ -674,16 +688,17 @@ def main():
                        "exchange": ("none (single process)" if not (world > 1 or forced) else
                                     "dsm_rccl: ncclAllGather from the library's callback, one communicator per lane" if native else
                                     "torch.distributed all_gather_into_tensor (%s) from a Python callback" % dist.get_backend())},
-            # `frac` is the hardware fraction: HBM bytes per launch as the PMC counters saw them (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-            # passes of this command, tools/profiling/r03_final.sh -> profiles/traffic.json; offline, but of this very kernel and
-            # workload) / the HIP-event time of this run's launches / 8 TB/s.  `model_*` = the bytes the kernel itself counted (64 B
-            # per distinct index block of a tile, handles, column entries, planes, records), live in this run.  Without a matching
-            # profile `frac` falls back to the model and says so in `frac_source`.
-            "roofline": {"bound": "hbm", "achieved": traffic_gbs if traffic_gbs is not None else ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (traffic_gbs if traffic_gbs is not None else ach) / HBM_PEAK_GBS,
-                         "frac_source": "pmc traffic (profiles/traffic.json) / live HIP-event time" if traffic_gbs is not None else "kernel byte counters / live HIP-event time",
-                         "traffic": traffic, "traffic_source": "profiles/traffic.json (offline rocprofv3 --pmc of the same command)" if traffic else None,
-                         "traffic_gbs": traffic_gbs,
+            # `achieved` / `frac`: live and self-counted -- the bytes the kernel itself counted in THIS run (64 B per distinct index block
+            # of a tile, handles, column entries, planes, records: the algorithmic bytes of DESIGN.md section 4) / the HIP-event time of
+            # this run's launches / 8 TB/s.  `traffic` / `pmc_*`: HBM bytes per launch as the PMC counters saw them (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE passes of this command, tools/profiling/r04_final.sh -> profiles/traffic.json), an OFFLINE figure
+            # that is quoted only when the profile was taken from this very kernel source (`kernel_sha16`), never mixed into `frac`.
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS,
+                         "frac_source": "kernel byte counters of this run / live HIP-event time",
+                         "traffic": traffic, "traffic_source": "profiles/traffic.json (offline rocprofv3 --pmc of the same command and kernel source)" if traffic else None,
+                         "pmc_gbs": traffic_gbs, "pmc_frac": traffic_gbs / HBM_PEAK_GBS if traffic_gbs is not None else None,
+                         "kernel_sha16": kernel_sha,
                          "model_gbs": ach, "model_frac": ach / HBM_PEAK_GBS,
                          "kernel": "expand_kernel (LF-step)", "launches": tot["launches"],
                          "avg_launch_ms": tot["expand_ms"] / max(1, tot["launches"]),                     # HIP events, this run
@@ -711,7 +726,9 @@ def main():
                        "format_ms_per_step": format_ms, "format_text_bytes_per_step": format_bytes,
                        "exchange_bytes_sent_per_step_rank0": tot["xsent"] / max(1, args.steps),
                        "exchange_bytes_received_per_step_rank0": tot["xrecv"] / max(1, args.steps),
-                       "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps)},
+                       "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps),
+                       # the exact entropy (metaserver.cpp:379,389) is the host's libm: its version goes next to every result
+                       "glibc": os.confstr("CS_GNU_LIBC_VERSION") if hasattr(os, "confstr") else None},
         }
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
         default_cfg = world == 1 and args.nlocal == 1 and not args.stream_mode and not forced

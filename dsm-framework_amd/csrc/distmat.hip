@@ -20,7 +20,30 @@ namespace dsm {
 int fail(int code, const std::string& m);  // index.hip
 
 constexpr int DM_THREADS = 256;
-constexpr u32 DM_LDS_CELLS = 1536;  // cells (count u32 + three doubles = 28 B) kept in LDS per block: 42 KB
+constexpr u32 DM_LDS_CELLS = 1024;  // cells (count u32 + three 128-bit sums = 52 B) kept in LDS per block: 52 KB
+
+// The three sums of squared distances are kept as 128-bit fixed-point numbers (64 integer bits, 64 fraction bits, two's complement)
+// and added with integer atomics: integer addition is associative, so a cell's sum does not depend on the order in which lanes,
+// blocks or batches reach it -- the matrices are the same from run to run (round 4; round 3 added doubles in whatever order the
+// atomics arrived, and the last printed digit could differ).  A term is a double; its bits below 2^-64 are dropped (the terms are
+// squares of differences of logs and roots of frequencies, and lgamma values: magnitudes between 1e-10 and 1e12), the sum itself
+// is exact, and it is rounded to a double once, at the end.
+struct Fix128 { unsigned long long lo, hi; };
+__device__ __forceinline__ void fix_add(Fix128* cell, double x) {
+    const double fl = floor(x);
+    const unsigned long long hi = (unsigned long long)(long long)fl;               // (two's complement of a negative integer part)
+    const unsigned long long lo = __double2ull_rz((x - fl) * 18446744073709551616.0);  // the fraction, in [0, 1), scaled by 2^64
+    const unsigned long long old = atomicAdd(&cell->lo, lo);
+    atomicAdd(&cell->hi, hi + ((old + lo) < old ? 1ull : 0ull));                    // carries commute with everything else
+}
+__device__ __forceinline__ void fix_merge(Fix128* cell, const Fix128& v) {
+    if (!v.lo && !v.hi) return;
+    const unsigned long long old = atomicAdd(&cell->lo, v.lo);
+    atomicAdd(&cell->hi, v.hi + ((old + v.lo) < old ? 1ull : 0ull));
+}
+static inline double fix_to_double(const Fix128& v) {   // (host) hi is signed, lo the fraction
+    return (double)(long long)v.hi + (double)v.lo * (1.0 / 18446744073709551616.0);
+}
 
 struct DmArgs {
     u32 nt;            // tuples of the batch
@@ -34,9 +57,9 @@ struct DmArgs {
     const u32* freqs;
     const signed char* bucket;  // per tuple, -1 = none
     u32* count;        // [nm][s][s]
-    double* mlog;
-    double* msqrt;
-    double* mlgamma;
+    Fix128* mlog;
+    Fix128* msqrt;
+    Fix128* mlgamma;
     const double* nfactor;  // -N: 1 / dataset size per sample (null: raw frequencies)
 };
 
@@ -60,12 +83,12 @@ __global__ __launch_bounds__(DM_THREADS) void distmat_kernel(DmArgs a) {
     u32* s_freq = reinterpret_cast<u32*>(smem);
     u32* s_pres = s_freq + groups * a.s;
     const u32 cells = a.nm * a.s * a.s;
-    double* l_log = reinterpret_cast<double*>(s_pres + groups * a.s + ((groups * a.s) & 1u));
-    double* l_sqrt = l_log + (a.use_lds ? cells : 0);
-    double* l_lgam = l_sqrt + (a.use_lds ? cells : 0);
+    Fix128* l_log = reinterpret_cast<Fix128*>(s_pres + groups * a.s);  // (groups is a power of two >= 4: 2 * groups * s words = a multiple of 8 bytes)
+    Fix128* l_sqrt = l_log + (a.use_lds ? cells : 0);
+    Fix128* l_lgam = l_sqrt + (a.use_lds ? cells : 0);
     u32* l_cnt = reinterpret_cast<u32*>(l_lgam + (a.use_lds ? cells : 0));
     if (a.use_lds)
-        for (u32 c = threadIdx.x; c < cells; c += DM_THREADS) { l_log[c] = 0; l_sqrt[c] = 0; l_lgam[c] = 0; l_cnt[c] = 0; }
+        for (u32 c = threadIdx.x; c < cells; c += DM_THREADS) { l_log[c] = Fix128{0, 0}; l_sqrt[c] = Fix128{0, 0}; l_lgam[c] = Fix128{0, 0}; l_cnt[c] = 0; }
     const u32 g = threadIdx.x / a.G, lane = threadIdx.x % a.G;
     u32* fq = s_freq + g * a.s;
     u32* pr = s_pres + g * a.s;
@@ -113,8 +136,8 @@ __global__ __launch_bounds__(DM_THREADS) void distmat_kernel(DmArgs a) {
                         ds = sqrt((double)fj) - sqrt((double)fk);
                         lg = lgamma((double)fj + (double)fk + 1.0) - lgamma((double)fj + 1.0) - lgamma((double)fk + 1.0) - ((double)fj + (double)fk + 1.0);
                     }
-                    if (a.use_lds) { atomicAdd(&l_log[cell], dl * dl); atomicAdd(&l_sqrt[cell], ds * ds); if (!a.nfactor) atomicAdd(&l_lgam[cell], lg); }
-                    else { atomicAdd(&a.mlog[cell], dl * dl); atomicAdd(&a.msqrt[cell], ds * ds); if (!a.nfactor) atomicAdd(&a.mlgamma[cell], lg); }
+                    if (a.use_lds) { fix_add(&l_log[cell], dl * dl); fix_add(&l_sqrt[cell], ds * ds); if (!a.nfactor) fix_add(&l_lgam[cell], lg); }
+                    else { fix_add(&a.mlog[cell], dl * dl); fix_add(&a.msqrt[cell], ds * ds); if (!a.nfactor) fix_add(&a.mlgamma[cell], lg); }
                 }
             }
         }
@@ -123,9 +146,9 @@ __global__ __launch_bounds__(DM_THREADS) void distmat_kernel(DmArgs a) {
     if (a.use_lds) {
         for (u32 c = threadIdx.x; c < cells; c += DM_THREADS) {
             if (l_cnt[c]) atomicAdd(&a.count[c], l_cnt[c]);
-            if (l_log[c] != 0) atomicAdd(&a.mlog[c], l_log[c]);
-            if (l_sqrt[c] != 0) atomicAdd(&a.msqrt[c], l_sqrt[c]);
-            if (l_lgam[c] != 0) atomicAdd(&a.mlgamma[c], l_lgam[c]);
+            fix_merge(&a.mlog[c], l_log[c]);
+            fix_merge(&a.msqrt[c], l_sqrt[c]);
+            fix_merge(&a.mlgamma[c], l_lgam[c]);
         }
     }
 }
@@ -144,7 +167,7 @@ struct dsm_distmat {
     std::vector<double> nfactor;      // -N: 1 / size
     double* d_nfactor = nullptr;
     u32* d_count = nullptr;
-    double *d_log = nullptr, *d_sqrt = nullptr, *d_lgamma = nullptr;
+    dsm::Fix128 *d_log = nullptr, *d_sqrt = nullptr, *d_lgamma = nullptr;  // 128-bit fixed-point sums (see Fix128)
     // upload staging (grown on demand)
     void *d_pair_off = nullptr, *d_ids = nullptr, *d_freqs = nullptr, *d_bucket = nullptr;
     size_t cap_t = 0, cap_p = 0;
@@ -206,8 +229,8 @@ int dsm_distmat_create_ex(int device, uint32_t samples, const double* maxent, ui
         for (u32 i = 0; i < samples; ++i) m->nfactor[i] = (double)1 / sizes[i];
     }
     const size_t cells = (size_t)nmaxent * samples * samples;
-    if (hipMalloc(&m->d_count, cells * 4) != hipSuccess || hipMalloc(&m->d_log, cells * 8) != hipSuccess ||
-        hipMalloc(&m->d_sqrt, cells * 8) != hipSuccess || hipMalloc(&m->d_lgamma, cells * 8) != hipSuccess) {
+    if (hipMalloc(&m->d_count, cells * 4) != hipSuccess || hipMalloc(&m->d_log, cells * 16) != hipSuccess ||
+        hipMalloc(&m->d_sqrt, cells * 16) != hipSuccess || hipMalloc(&m->d_lgamma, cells * 16) != hipSuccess) {
         dsm_distmat_destroy(m);
         return fail(DSM_E_NOMEM, "hipMalloc failed");
     }
@@ -215,8 +238,8 @@ int dsm_distmat_create_ex(int device, uint32_t samples, const double* maxent, ui
         if (hipMalloc(&m->d_nfactor, samples * 8) != hipSuccess) { dsm_distmat_destroy(m); return fail(DSM_E_NOMEM, "hipMalloc failed"); }
         (void)hipMemcpy(m->d_nfactor, m->nfactor.data(), samples * 8, hipMemcpyHostToDevice);
     }
-    (void)hipMemset(m->d_count, 0, cells * 4); (void)hipMemset(m->d_log, 0, cells * 8);
-    (void)hipMemset(m->d_sqrt, 0, cells * 8); (void)hipMemset(m->d_lgamma, 0, cells * 8);
+    (void)hipMemset(m->d_count, 0, cells * 4); (void)hipMemset(m->d_log, 0, cells * 16);
+    (void)hipMemset(m->d_sqrt, 0, cells * 16); (void)hipMemset(m->d_lgamma, 0, cells * 16);
     *out = m;
     return DSM_OK;
 }
@@ -360,7 +383,7 @@ static int dm_accumulate(dsm_distmat* m, size_t nt, const u32* pair_off, const u
     a.bucket = (const signed char*)m->d_bucket;
     a.count = m->d_count; a.mlog = m->d_log; a.msqrt = m->d_sqrt; a.mlgamma = m->d_lgamma; a.nfactor = m->d_nfactor;
     const u32 groups = DM_THREADS / G;
-    size_t shm = (size_t)groups * s * 8 + 8 + (a.use_lds ? (size_t)cells * 28 : 0);
+    size_t shm = (size_t)groups * s * 8 + 24 + (a.use_lds ? (size_t)cells * 52 : 0);
     u64 blocks = (nt + groups - 1) / groups;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(distmat_kernel, dim3((unsigned)blocks), dim3(DM_THREADS), shm, 0, a);
@@ -419,9 +442,15 @@ int dsm_distmat_finish(dsm_distmat* m, double* maxent_sorted, uint32_t* noutput,
     std::vector<u32> c(cells);
     std::vector<double> l(cells), q(cells), g(cells);
     DM_HIP(hipMemcpy(c.data(), m->d_count, cells * 4, hipMemcpyDeviceToHost));
-    DM_HIP(hipMemcpy(l.data(), m->d_log, cells * 8, hipMemcpyDeviceToHost));
-    DM_HIP(hipMemcpy(q.data(), m->d_sqrt, cells * 8, hipMemcpyDeviceToHost));
-    DM_HIP(hipMemcpy(g.data(), m->d_lgamma, cells * 8, hipMemcpyDeviceToHost));
+    {
+        std::vector<Fix128> f(cells);
+        DM_HIP(hipMemcpy(f.data(), m->d_log, cells * 16, hipMemcpyDeviceToHost));
+        for (size_t x = 0; x < cells; ++x) l[x] = fix_to_double(f[x]);
+        DM_HIP(hipMemcpy(f.data(), m->d_sqrt, cells * 16, hipMemcpyDeviceToHost));
+        for (size_t x = 0; x < cells; ++x) q[x] = fix_to_double(f[x]);
+        DM_HIP(hipMemcpy(f.data(), m->d_lgamma, cells * 16, hipMemcpyDeviceToHost));
+        for (size_t x = 0; x < cells; ++x) g[x] = fix_to_double(f[x]);
+    }
     std::vector<u32> nout = m->noutput;
     for (u32 i = m->nm; i > 1;) {  // accumulate(i -> i-1), smtxt2entropy.c:230-242, in the print loop's order (:746-750)
         --i;

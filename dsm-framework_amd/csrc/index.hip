@@ -388,6 +388,19 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
         if (!nodes.empty() && !nodes[0].leaf && nodes[0].nbits != m.n) return fail(DSM_E_FORMAT, "root bitvector length != n");
     }
 
+    // A version-14 file keeps C[] in 32 bits: past 2^32 symbols the values wrapped.  The reference notices a C[] that is not
+    // monotone and recounts the symbols through the wavelet tree (FMIndex.cpp:346-356 -> recomputeC, :219-237: C[i] = symbols smaller
+    // than i).  The same numbers follow from the code table's counts, which were just checked to add up to n (counts that wrapped as
+    // well fail that check above and the file is refused).  (The reference also saves the repaired index as <name>.reC; this library
+    // never writes next to its inputs.)
+    for (int i = 1; i < 256; ++i) {
+        if (m.C[i] < m.C[i - 1]) {
+            u64 run = 0;
+            for (int j = 0; j < 256; ++j) { m.C[j] = run; run += m.codes[j].count; }
+            break;
+        }
+    }
+
     // symbol -> 3-bit code
     for (int i = 0; i < 256; ++i) m.byte2code[i] = -1;
     const char* bases = "ACGT";

@@ -144,6 +144,18 @@ struct Index {
         (void)r.rd<uint32_t>();  // rotationLength
         if (!r.ok) { g_err = "file read error (truncated .fmi)"; return false; }
         if (nameFlag || tsFlag) { g_err = ".fmi with name/text storage is not produced by builder; unsupported"; return false; }
+        // FMIndex.cpp:346-356: a C[] with truncated (32-bit, version 14) values is recounted through the wavelet tree
+        // (recomputeC, FMIndex.cpp:219-237); the reference also saves the repaired index as <name>.reC, which a checker does not.
+        for (int i = 1; i < 256; ++i) {
+            if (C[i] < C[i - 1]) {
+                for (int j = 0; j < 256; ++j) C[j] = 0;
+                for (u64 k = 0; k < n; ++k) C[(int)access(k, nullptr)]++;
+                u64 prev = C[0], temp;
+                C[0] = 0;
+                for (int j = 1; j < 256; ++j) { temp = C[j]; C[j] = C[j - 1] + prev; prev = temp; }
+                break;
+            }
+        }
         return true;
     }
 

@@ -110,6 +110,16 @@ def test_gpu_distmat_matches_oracle_on_goldens(setname, case, pydsm_mod):
         dm.add_text(text[half:])
         res = dm.finish()
     _cmp(res, nout, cnt, mats)
+    # the sums are exact 128-bit fixed-point sums, rounded once (distmat.hip, Fix128): they do not depend on how the lines are cut
+    # into batches, on the order the blocks run in, or on the run -- bit for bit
+    with pydsm_mod.DistMat(smpls, maxent=maxent, minfreq=minfreq, run_to_sample=mapping, sizes=sizes) as dm:
+        cuts = [0] + [text.rfind(b"\n", 0, len(text) * k // 5) + 1 for k in range(1, 5)] + [len(text)]
+        for a, b in zip(cuts, cuts[1:]):
+            if b > a:
+                dm.add_text(text[a:b])
+        res2 = dm.finish()
+    for k in ("count", "log", "sqrt", "lgamma"):
+        assert np.array_equal(res[k], res2[k]), k
     got = pydsm_mod.DistMat.format(res)
     assert got[0] == texts[0]             # the count file is exact
     for g, w in zip(got[1:], texts[1:]):  # the double files agree line for line up to the last printed digits

@@ -315,6 +315,22 @@ def test_older_fmi_versions_and_degenerate_alphabets(golden, pydsm_mod, tmp_path
             assert got[got.index(b"."):] == want[want.index(b"."):]     # same node stream (the sample name differs)
             assert got == o.enumerate(g.name, "GT", fmin=2)[0]
         o.close()
+    # a version-14 file whose 32-bit C[] wrapped (FMIndex.cpp:346-356: the reference recounts it; here the wrap is played at 6 bits on
+    # the toy index): the loader repairs it from the code table, the oracle as the reference does, and both give the pristine stream
+    import struct
+    v14 = bytearray(_downgrade_fmi(raw, 14))
+    C = list(struct.unpack_from("<256I", v14, 13))
+    assert any(c >= 64 for c in C)
+    struct.pack_into("<256I", v14, 13, *[c % 64 for c in C])
+    p = tmp_path / "wrapped.toy-2.fasta.fmi"
+    p.write_bytes(bytes(v14))
+    o = orc.Index(str(p))
+    with pydsm_mod.Index(str(p)) as g:
+        got, _ = g.enumerate("GT", fmin=2)
+        assert got[got.index(b"."):] == want[want.index(b"."):]
+        assert got == o.enumerate(g.name, "GT", fmin=2)[0]
+        assert g.check() == g.n
+    o.close()
     ref.close()
     # reads without any A,C,G,T: nothing to enumerate, LF still answers for the symbols that exist
     from pydsm import builder
@@ -416,3 +432,13 @@ def test_seventy_and_273_samples_against_oracle(pydsm_mod, tmp_path):
             assert got == want and st.tuples == ost[4], (d, p, "pmax=1")
         for ix in idx + oidx:
             ix.close()
+
+
+def test_glibc_of_the_gpu_box_is_recent_enough():
+    """The exact entropy (metaserver.cpp:379,389) and the keep table of the LF-step kernel are computed with the box's libm: glibc's
+    log() is the correctly rounded-in-practice implementation since 2.28 (the goldens were made with 2.35, tests/golden/MANIFEST.json);
+    an older libm could print a different last digit.  bench.py records the version in `detail.glibc`."""
+    v = os.confstr("CS_GNU_LIBC_VERSION")
+    assert v and v.startswith("glibc "), v
+    major, minor = (int(x) for x in v.split()[1].split(".")[:2])
+    assert (major, minor) >= (2, 28), v
