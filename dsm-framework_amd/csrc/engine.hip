@@ -4074,64 +4074,5 @@ uint64_t dsm_server_units(const dsm_server* sv, uint64_t* peak_unit_nodes) {
 }
 void dsm_server_destroy(dsm_server* sv) { delete sv; }
 
-int dsm_format_batch(const dsm_tuple_batch* b, char** text, size_t* len) {  // metaserver.cpp:472-484
-    if (!b || !text || !len) return fail(DSM_E_INVAL, "dsm_format_batch: null argument");
-    // printf's "%f" per tuple is the expensive part (one thread: 6 M lines/s, the mining delivers 100 M tuples/s): the tuples
-    // are formatted in ranges by several threads, each into its own worst-case window of the output, then moved together.
-    const u64 nt = b->ntuples;
-    unsigned nth = host_threads();
-    if (nt < 65536) nth = 1;
-    std::vector<size_t> cap(nth + 1, 0), used(nth, 0);
-    auto range = [&](unsigned t, u64& lo, u64& hi) { lo = nt * t / nth; hi = nt * (t + 1) / nth; };
-    for (unsigned t = 0; t < nth; ++t) {
-        u64 lo, hi;
-        range(t, lo, hi);
-        size_t c = 0;
-        if (hi > lo) c = (size_t)(b->path_off[hi] - b->path_off[lo]) + (size_t)(hi - lo) * 48 + (size_t)(b->pair_off[hi] - b->pair_off[lo]) * 34;
-        cap[t + 1] = cap[t] + c;
-    }
-    char* out = (char*)malloc(cap[nth] + 64);
-    if (!out) return fail(DSM_E_NOMEM, "malloc failed");
-    std::atomic<int> bad{0};  // a caller-made batch whose numbers do not fit the windows (an entropy of 1e300 prints 300 digits)
-    auto work = [&](unsigned t) {
-        u64 lo, hi;
-        range(t, lo, hi);
-        char* o = out + cap[t];
-        const size_t room = cap[t + 1] - cap[t] + (t + 1 == nth ? 64 : 0);
-        size_t w = 0;
-        for (u64 r = lo; r < hi && !bad; ++r) {
-            size_t pl = b->path_off[r + 1] - b->path_off[r];
-            memcpy(o + w, b->path_bytes + b->path_off[r], pl);
-            w += pl;
-            int k = snprintf(o + w, room - w, " %f", b->entropy[r]);
-            if (k < 0 || (size_t)k >= room - w) { bad = 1; break; }
-            w += (size_t)k;
-            for (u32 q = b->pair_off[r]; q < b->pair_off[r + 1] && !bad; ++q) {
-                k = snprintf(o + w, room - w, " %d:%lu", (int)b->ids[q], (unsigned long)b->freqs[q]);
-                if (k < 0 || (size_t)k + 1 >= room - w) { bad = 1; break; }
-                w += (size_t)k;
-            }
-            if (bad) break;
-            o[w++] = '\n';
-        }
-        used[t] = w;
-    };
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nth; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
-    if (bad) { free(out); return fail(DSM_E_INVAL, "dsm_format_batch: a value does not fit its text window (entropy out of range?)"); }
-    size_t w = used[0];
-    for (unsigned t = 1; t < nth; ++t) {  // close the gaps between the windows
-        memmove(out + w, out + cap[t], used[t]);
-        w += used[t];
-    }
-    out[w] = 0;
-    *text = out;
-    *len = w;
-    return DSM_OK;
-}
 
 }  // extern "C"

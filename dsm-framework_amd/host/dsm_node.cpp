@@ -38,13 +38,24 @@ static FILE* g_out = nullptr;
 
 static const char* USAGE = "usage: dsm_node -E emax [options] [--devices D0,D1,..] -p PREFIX[,PREFIX..] a.fmi b.fmi ...";
 
+// The lines of metaserver.cpp:472-484 come from the GPU (dsm_formatter_*: byte for byte the reference's printf loop); a formatter
+// belongs to the sink that uses it (one emitter thread per miner calls a sink).
+struct Fmt {
+    dsm_formatter* f = nullptr;
+    int device = 0;
+    int text(const dsm_tuple_batch* b, const char** t, size_t* n) {
+        if (!f && dsm_formatter_create(device, &f)) return 1;
+        return dsm_formatter_format(f, b, t, n);
+    }
+    ~Fmt() { if (f) dsm_formatter_destroy(f); }
+};
+static Fmt g_fmt;  // the single-device run's
+
 static int to_file(void* ctx, const dsm_tuple_batch* b) {
-    char* text = nullptr;
+    const char* text = nullptr;
     size_t len = 0;
-    if (dsm_format_batch(b, &text, &len)) return 1;
-    size_t w = fwrite(text, 1, len, (FILE*)ctx);
-    dsm_free(text);
-    return w != len;
+    if (g_fmt.text(b, &text, &len)) return 1;
+    return fwrite(text, 1, len, (FILE*)ctx) != len;
 }
 
 // ---- several devices ---------------------------------------------------------------------------------------------------
@@ -63,6 +74,7 @@ struct Rendezvous {
 };
 
 struct Rank {
+    Fmt fmt;
     int rank = 0, world = 1, device = 0;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
@@ -94,11 +106,10 @@ static int to_prefix_text(void* ctx, const dsm_tuple_batch* b) {
         if (pre.size() <= plen && memcmp(pre.data(), path, pre.size()) == 0 && (best < 0 || pre.size() > (*r->prefixes)[best].size())) best = (int)k;
     }
     if (best < 0) return 1;
-    char* text = nullptr;
+    const char* text = nullptr;
     size_t len = 0;
-    if (dsm_format_batch(b, &text, &len)) return 1;
+    if (r->fmt.text(b, &text, &len)) return 1;
     (*r->out)[best].append(text, len);
-    dsm_free(text);
     return 0;
 }
 
@@ -168,7 +179,7 @@ static int run_devices(const std::vector<int>& devs, const dsm_params& p, const 
     meet.expected = G;
     for (int r = 0; r < G; ++r) {
         ranks[r].meet = &meet;
-        ranks[r].rank = r; ranks[r].world = G; ranks[r].device = devs[r]; ranks[r].comm = comms[r];
+        ranks[r].rank = r; ranks[r].world = G; ranks[r].device = devs[r]; ranks[r].fmt.device = devs[r]; ranks[r].comm = comms[r];
         ranks[r].files.assign(files.begin() + r * nlocal, files.begin() + (r + 1) * nlocal);
         ranks[r].prefixes = &prefixes; ranks[r].out = &out; ranks[r].p = p;
     }
@@ -198,6 +209,7 @@ static int run_devices(const std::vector<int>& devs, const dsm_params& p, const 
 
 // ---- several devices, owner mode ------------------------------------------------------------------------------------------
 struct LaneRank {
+    Fmt fmt;
     int rank = 0, lane = 0, world = 1, device = 0;
     dsm_rccl* comm = nullptr;
     dsm_rccl_gate* gate = nullptr;
@@ -219,11 +231,10 @@ static int to_lane_text(void* ctx, const dsm_tuple_batch* b) {
         if (pre.size() <= plen && memcmp(pre.data(), path, pre.size()) == 0) best = (int)k;
     }
     if (best < 0) return 1;
-    char* text = nullptr;
+    const char* text = nullptr;
     size_t len = 0;
-    if (dsm_format_batch(b, &text, &len)) return 1;
+    if (r->fmt.text(b, &text, &len)) return 1;
     (*r->out)[best].append(text, len);
-    dsm_free(text);
     return 0;
 }
 
@@ -248,7 +259,7 @@ static int run_devices_owner(const std::vector<int>& devs, const dsm_params& p0,
         for (size_t k = j; k < prefixes.size(); k += G) mine.push_back(prefixes[k]);
         outs[j].resize(mine.size());
         for (int r = 0; r < G; ++r) {
-            lr[r][j].rank = r; lr[r][j].lane = j; lr[r][j].world = G; lr[r][j].device = devs[r];
+            lr[r][j].rank = r; lr[r][j].lane = j; lr[r][j].world = G; lr[r][j].device = devs[r]; lr[r][j].fmt.device = devs[r];
             lr[r][j].prefixes = mine; lr[r][j].out = &outs[j];
         }
     }
@@ -394,6 +405,15 @@ int main(int argc, char** argv) {
     }
     dsm_miner* m = nullptr;
     if (dsm_miner_create(idx.data(), (int)idx.size(), &p, 0, &m)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+    g_fmt.device = device;
+    if (outprefix.empty()) {  // everything to one stream: one call, so that the tuples of a prefix leave while the next one is expanded
+        std::vector<const char*> ps;
+        for (const std::string& one : pre) ps.push_back(one.c_str());
+        dsm_stats st;
+        if (dsm_miner_mine_many(m, ps.data(), (int)ps.size(), to_file, g_out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+        std::cerr << pre.size() << " prefix(es): " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported" << std::endl;
+        pre.clear();
+    }
     for (const std::string& one : pre) {
         FILE* out = g_out;
         if (!outprefix.empty()) {

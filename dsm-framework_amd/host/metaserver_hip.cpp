@@ -25,13 +25,15 @@
 
 #include "../../include/dsmhip.h"
 
-static int print_batch(void*, const dsm_tuple_batch* b) {  // metaserver.cpp:472-484
-    char* text = nullptr;
+// metaserver.cpp:472-484: the lines are formatted on the GPU (dsm_formatter_*: the bytes of the reference's printf loop)
+static dsm_formatter* g_fmt = nullptr;
+static int g_fmt_device = 0;
+static int print_batch(void*, const dsm_tuple_batch* b) {
+    if (!g_fmt && dsm_formatter_create(g_fmt_device, &g_fmt)) return 1;
+    const char* text = nullptr;
     size_t len = 0;
-    if (dsm_format_batch(b, &text, &len)) return 1;
-    size_t w = fwrite(text, 1, len, stdout);
-    dsm_free(text);
-    return w != len;
+    if (dsm_formatter_format(g_fmt, b, &text, &len)) return 1;
+    return fwrite(text, 1, len, stdout) != len;
 }
 
 int main(int argc, char** argv) {
@@ -93,6 +95,7 @@ int main(int argc, char** argv) {
     std::vector<bool> seen(d, false);
     std::vector<std::thread> readers;
     dsm_server* srv = nullptr;
+    g_fmt_device = device;
     if (dsm_server_create((int)d, device, prefix_len, unit_extra, &p, print_batch, nullptr, &srv)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
     std::string perr;
     std::mutex err_mu;

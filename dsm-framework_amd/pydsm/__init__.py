@@ -143,6 +143,11 @@ def lib():
         L.dsm_server_destroy.argtypes = [C.c_void_p]
         L.dsm_server_destroy.restype = None
         L.dsm_format_batch.argtypes = [C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.dsm_format_batch_dev.argtypes = [C.POINTER(TupleBatch), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.dsm_formatter_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_formatter_format.argtypes = [C.c_void_p, C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.dsm_formatter_destroy.argtypes = [C.c_void_p]
+        L.dsm_formatter_destroy.restype = None
         L.dsm_free.argtypes = [C.c_void_p]
         L.dsm_index_offload.argtypes = [C.c_void_p]
         L.dsm_index_reload.argtypes = [C.c_void_p, C.c_void_p]
@@ -171,6 +176,7 @@ class Index:
     def __init__(self, path, device=0, keep_wt=False):
         self.h = C.c_void_p()
         _check(lib().dsm_index_open_ex(os.fsencode(path), device, OPEN_KEEP_WT if keep_wt else 0, C.byref(self.h)))
+        self.device = int(device)
         self.n = lib().dsm_index_length(self.h)
         self.name = lib().dsm_index_name(self.h).decode()
         self.device = device
@@ -374,25 +380,69 @@ class RcclComm:
             self.h = C.c_void_p()
 
 
-def _tuple_sink(out, text, on_batch, err):
+class Formatter:
+    """metaserver's output text of tuple batches from the GPU (dsm_formatter_*): the bytes of dsm_format_batch's snprintf loop."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().dsm_formatter_create(device, C.byref(self.h)))
+
+    def format(self, batch):
+        """batch: a TupleBatch (or a pointer to one, as a sink receives it) -> bytes"""
+        t = C.c_void_p()
+        n = C.c_size_t(0)
+        _check(lib().dsm_formatter_format(self.h, batch, C.byref(t), C.byref(n)))
+        return C.string_at(t, n.value) if n.value else b""
+
+    def close(self):
+        if self.h:
+            lib().dsm_formatter_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+TEXT_ON_HOST = bool(os.environ.get("DSM_TEXT_HOST"))  # the tuple text of mine()/merge()/Server from the host's snprintf loop instead of the GPU
+
+
+def _tuple_sink(out, text, on_batch, err, device=0):
     """err: a list that receives the exception a callback raised.  An exception must not unwind through C (ctypes would print
-    it and report success): the sink returns 1 instead, the library fails with DSM_E_SINK and the caller re-raises."""
+    it and report success): the sink returns 1 instead, the library fails with DSM_E_SINK and the caller re-raises.
+    The text comes from the device formatter (dsm_formatter_format), one formatter per sink, created at the first batch."""
+    fmt = []
+
     def sink(ctx, b):
         try:
             if on_batch is not None:
                 on_batch(b.contents)
             if text:
-                t = C.c_void_p()
-                n = C.c_size_t(0)
-                if lib().dsm_format_batch(b, C.byref(t), C.byref(n)) != 0:
-                    return 1
-                out.append(C.string_at(t, n.value))
-                lib().dsm_free(t)
+                if TEXT_ON_HOST:
+                    t = C.c_void_p()
+                    n = C.c_size_t(0)
+                    if lib().dsm_format_batch(b, C.byref(t), C.byref(n)) != 0:
+                        return 1
+                    out.append(C.string_at(t, n.value))
+                    lib().dsm_free(t)
+                else:
+                    if not fmt:
+                        fmt.append(Formatter(device))
+                    out.append(fmt[0].format(b))
             return 0
         except BaseException as e:  # noqa: BLE001
             err.append(e)
             return 1
-    return TUPLE_SINK(sink)
+    cb = TUPLE_SINK(sink)
+    cb._dsm_formatters = fmt  # (closed by _close_sink after the call that used the sink)
+    return cb
+
+
+def _close_sink(cb):
+    for f in getattr(cb, "_dsm_formatters", []):
+        f.close()
 
 
 def _check_sink(rc, err):
@@ -417,20 +467,29 @@ class Miner:
         self.h = C.c_void_p()
         _check(lib().dsm_miner_create(hs, len(indexes), C.byref(p), 1 if stream_mode else 0, C.byref(self.h)))
 
+    def _device(self):
+        return int(getattr(self.indexes[0], "device", 0)) if self.indexes else 0
+
     def mine(self, prefix, text=True, on_batch=None):
         out, err = [], []
-        cb = _tuple_sink(out, text, on_batch, err)
+        cb = _tuple_sink(out, text, on_batch, err, self._device())
         st = Stats()
-        _check_sink(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)), err)
+        try:
+            _check_sink(lib().dsm_miner_mine(self.h, prefix.encode(), cb, None, C.byref(st)), err)
+        finally:
+            _close_sink(cb)
         return (b"".join(out) if text else None), st
 
     def mine_many(self, prefixes, text=True, on_batch=None):
         """All prefixes in one call (host emission of prefix k overlaps GPU work on prefix k+1)."""
         out, err = [], []
-        cb = _tuple_sink(out, text, on_batch, err)
+        cb = _tuple_sink(out, text, on_batch, err, self._device())
         st = Stats()
         arr = (C.c_char_p * len(prefixes))(*[p.encode() for p in prefixes])
-        _check_sink(lib().dsm_miner_mine_many(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
+        try:
+            _check_sink(lib().dsm_miner_mine_many(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
+        finally:
+            _close_sink(cb)
         return (b"".join(out) if text else None), st
 
     def enumerate(self, prefix, with_header=True, discard=False):
@@ -521,7 +580,10 @@ def mine(indexes, prefix, fmin=10, maxdepth=MAXDEPTH_NONE, pmin=2, pmax=0, minde
     cb = _tuple_sink(out, text, on_batch, err)
     hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
     st = Stats()
-    _check_sink(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)), err)
+    try:
+        _check_sink(lib().dsm_mine(hs, len(indexes), C.byref(p), cb, None, C.byref(st)), err)
+    finally:
+        _close_sink(cb)
     return (b"".join(out) if text else None), st
 
 
@@ -569,7 +631,10 @@ def merge(tries, pmin=2, pmax=0, mindepth=0, emin=0.0, emax=-1.0, arena_bytes=0,
     cb = _tuple_sink(out, text, on_batch, err)
     hs = (C.c_void_p * len(tries))(*[t.h for t in tries])
     st = Stats()
-    _check_sink(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)), err)
+    try:
+        _check_sink(lib().dsm_merge(hs, len(tries), C.byref(p), cb, None, C.byref(st)), err)
+    finally:
+        _close_sink(cb)
     return (b"".join(out) if text else None), st
 
 
@@ -609,6 +674,7 @@ class Server:
         if self.h:
             lib().dsm_server_destroy(self.h)
             self.h = C.c_void_p()
+            _close_sink(self._cb)
 
 
 class DistMat:

@@ -309,6 +309,17 @@ void dsm_miner_destroy(dsm_miner* m);
  * *text is malloc'd; release with dsm_free. */
 int dsm_format_batch(const dsm_tuple_batch* batch, char** text, size_t* len);
 void dsm_free(void* p);
+/* The same bytes from the GPU (metaserver.cpp:472-484 is 5x the mining pass when one host thread per core does it): one thread per
+ * tuple measures its line, a scan places the lines, one thread per tuple writes.  "%f" is exact: the double's significand times 10^6
+ * as a 128-bit integer, shifted by the binary exponent, rounded half to even -- what glibc's printf prints; a batch with a value of
+ * 2^40 or more, an infinity or a NaN in its entropy column (never an entropy) is formatted by dsm_format_batch instead.
+ * A formatter keeps its device and pinned buffers between calls; *text stays valid until the next call on the formatter (or its
+ * destruction) and is NUL-terminated.  dsm_format_batch_dev: one-shot form, *text malloc'd, release with dsm_free. */
+typedef struct dsm_formatter dsm_formatter;
+int dsm_formatter_create(int device, dsm_formatter** out);
+int dsm_formatter_format(dsm_formatter* f, const dsm_tuple_batch* batch, const char** text, size_t* len);
+void dsm_formatter_destroy(dsm_formatter* f);
+int dsm_format_batch_dev(const dsm_tuple_batch* batch, int device, char** text, size_t* len);
 
 /* ------------------------------------------------------------------------------------------------
  * Index construction: the multi-string BWT the reference builder computes with incbwt

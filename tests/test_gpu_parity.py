@@ -2,6 +2,8 @@
 on the same inputs and against the committed reference goldens.  Bit-exact (integer/byte work; the
 entropy is IEEE double computed as metaserver.cpp:379,389 -- compared through its %f text AND raw bits
 of the oracle's server output)."""
+import os
+
 import numpy as np
 import pytest
 
