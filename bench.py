@@ -634,7 +634,7 @@ def main():
     # calls alone (`format_ms_per_step`) and the whole pass (`text_pass_ms`: what a user of the text surface waits for; the formatter's
     # transfers share the bus with the next prefix's tuples).  `format_host_ms_per_step`: the same text from the host's snprintf loop,
     # on a tenth of the batches, scaled -- the round-3 path, kept as the checker.
-    format_ms, format_bytes, text_pass_ms, format_host_ms = None, 0, None, None
+    format_ms, format_bytes, text_pass_ms, format_host_ms, text_pass_formatter_ms, text_mode_bytes = None, 0, None, None, None, None
     if rank == 0 and world == 1 and not args.stream_mode and not forced and not args.no_cpu:  # (--no-cpu: profiling runs, exactly steps + warmup passes)
         import ctypes as C
         acc = {"s": 0.0, "bytes": 0, "host_s": 0.0, "host_bytes": 0, "k": 0}
@@ -675,7 +675,20 @@ def main():
             t1 = time.perf_counter()
             lanes[0]["miner"].mine_many(lanes[0]["prefixes"], text=False, on_batch=fmt_only)
             torch.cuda.synchronize()
+            text_pass_formatter_ms = (time.perf_counter() - t1) * 1e3
+            # ... and the text mode of the emitter (dsm_miner_mine_text: entropy, filter and lines on the card, only text over the bus):
+            # what dsm_node does
+            acc3 = {"bytes": 0}
+
+            def count(ptr, n):  # (a sink that takes the bytes where the library left them, as fwrite would)
+                acc3["bytes"] += n
+            lanes[0]["miner"].mine_text(lanes[0]["prefixes"], on_raw=count)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            lanes[0]["miner"].mine_text(lanes[0]["prefixes"], on_raw=count)
+            torch.cuda.synchronize()
             text_pass_ms = (time.perf_counter() - t1) * 1e3
+            text_mode_bytes = acc3["bytes"] // 2
         fm.close()
     for ln in lanes:
         ln["miner"].close()
@@ -751,7 +764,7 @@ def main():
                        "union_nodes_per_step": tot["union"] / max(1, args.steps), "candidates_per_step": tot["cand"] / max(1, args.steps),
                        "expand_ms_per_step": tot["expand_ms"] / max(1, args.steps), "device_ms_per_step": tot["device_ms"] / max(1, args.steps),
                        "host_ms_per_step": tot["host_ms"] / max(1, args.steps), "index_build_s": build_s,
-                       "format_ms_per_step": format_ms, "format_text_bytes_per_step": format_bytes, "text_pass_ms": text_pass_ms,
+                       "format_ms_per_step": format_ms, "format_text_bytes_per_step": format_bytes, "text_pass_ms": text_pass_ms, "text_pass_bytes": text_mode_bytes, "text_pass_with_formatter_sink_ms": text_pass_formatter_ms,
                        "format_host_ms_per_step": format_host_ms,
                        "exchange_bytes_sent_per_step_rank0": tot["xsent"] / max(1, args.steps),
                        "exchange_bytes_received_per_step_rank0": tot["xrecv"] / max(1, args.steps),

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "scan.h"
 #include "fmt6.h"
+#include "entropy_tables.h"
+#include "textemit.h"
 
 namespace dsm {
 
@@ -108,6 +110,206 @@ struct GrowPin {
     }
     ~GrowPin() { if (p) (void)hipHostFree(p); }
 };
+
+
+// ---- text mode of the emitter (textemit.h) ---------------------------------------------------------------------------------
+// entropy of tuple r exactly as emit_job computes it on the host: the same table entries added in the same order, one division, one
+// subtraction (IEEE double, no contraction).  A frequency or a total outside the tables makes the tuple an exception: the host
+// computes those with libm (a few hundred nodes at the top of a pass) and writes them back.
+constexpr u8 TE_DROP = 0, TE_KEEP = 1, TE_HOST = 2;
+__global__ __launch_bounds__(256) void te_entropy_kernel(u32 t0, u32 t1, const u32* __restrict__ pair_off, const u64* __restrict__ freqs, u32 d, double emin,
+                                                         double emax, const double* __restrict__ terms, const double* __restrict__ logn, double* __restrict__ ent,
+                                                         u8* __restrict__ keep, u32* __restrict__ nexc, u32* __restrict__ exc, u32 exc_cap) {
+    const u32 r = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t1) return;
+    u64 sumN = d;
+    double s = 0;
+    bool host = false;
+    for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
+        const u64 f = freqs[q];
+        sumN += f;
+        if (f >= TERM_TAB) { host = true; break; }
+        s += terms[f];
+    }
+    if (sumN >= LOGN_TAB) host = true;
+    if (host) {
+        const u32 k = atomicAdd(nexc, 1u);
+        if (k < exc_cap) exc[k] = r;
+        keep[r - t0] = TE_HOST;
+        return;
+    }
+    const double e = logn[sumN] - s / (double)sumN;
+    ent[r - t0] = e;
+    keep[r - t0] = (emax > 0 && (e < emin || e > emax)) ? TE_DROP : TE_KEEP;
+}
+// the frequencies of the exceptions, for the host: row i = count, then the frequencies in order
+constexpr u32 TE_ROW = 280;  // >= 1 + MAX_READERS (273)
+__global__ void te_gather_kernel(u32 n, const u32* __restrict__ exc, const u32* __restrict__ pair_off, const u64* __restrict__ freqs, u64* __restrict__ rows) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = exc[i], q0 = pair_off[r], q1 = pair_off[r + 1];
+    u32 c = q1 - q0;
+    if (c > TE_ROW - 1) c = TE_ROW - 1;
+    rows[(size_t)i * TE_ROW] = c;
+    for (u32 k = 0; k < c; ++k) rows[(size_t)i * TE_ROW + 1 + k] = freqs[q0 + k];
+}
+__global__ void te_scatter_kernel(u32 n, u32 t0, const u32* __restrict__ exc, const double* __restrict__ val, double emin, double emax, double* __restrict__ ent,
+                                  u8* __restrict__ keep) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = exc[i];
+    const double e = val[i];
+    ent[r - t0] = e;
+    keep[r - t0] = (emax > 0 && (e < emin || e > emax)) ? TE_DROP : TE_KEEP;
+}
+// length of a kept tuple's line (0: dropped); the kept tuples and pairs are counted
+__global__ __launch_bounds__(256) void te_len_kernel(u32 t0, u32 t1, const u32* __restrict__ path_off, const u32* __restrict__ pair_off, const u32* __restrict__ ids,
+                                                     const u64* __restrict__ freqs, const double* __restrict__ ent, const u8* __restrict__ keep,
+                                                     u32* __restrict__ len, unsigned long long* __restrict__ counts, u32* __restrict__ bad) {
+    const u32 r = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t1) return;
+    if (keep[r - t0] != TE_KEEP) { len[r - t0] = 0; return; }
+    bool neg, ok;
+    const u64 v = fixed6_of(ent[r - t0], &neg, &ok);
+    if (!ok) { atomicOr(bad, 1u); len[r - t0] = 0; return; }  // (an entropy is at most log2(273): cannot happen)
+    u32 n = (path_off[r + 1] - path_off[r]) + 1u + (neg ? 1u : 0u) + dec_digits(v / 1000000ull) + 7u;
+    for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) n += 2u + dec_digits(ids[q]) + dec_digits(freqs[q]);
+    len[r - t0] = n + 1u;
+    atomicAdd(counts, 1ull);
+    atomicAdd(counts + 1, (unsigned long long)(pair_off[r + 1] - pair_off[r]));
+}
+__global__ __launch_bounds__(256) void te_write_kernel(u32 t0, u32 t1, const u32* __restrict__ path_off, const char* __restrict__ paths, const u32* __restrict__ pair_off,
+                                                       const u32* __restrict__ ids, const u64* __restrict__ freqs, const double* __restrict__ ent,
+                                                       const u32* __restrict__ len, const u64* __restrict__ off, char* __restrict__ out) {
+    const u32 r = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t1 || len[r - t0] == 0) return;
+    char* p = out + off[r - t0];
+    const u32 pb = path_off[r], pl = path_off[r + 1] - pb;
+    for (u32 k = 0; k < pl; ++k) p[k] = paths[pb + k];
+    p += pl;
+    *p++ = ' ';
+    bool neg, ok;
+    const u64 v = fixed6_of(ent[r - t0], &neg, &ok);
+    if (neg) *p++ = '-';
+    const u64 ip = v / 1000000ull;
+    u32 fr = (u32)(v % 1000000ull);
+    p += put_dec(p, ip, dec_digits(ip));
+    *p++ = '.';
+    for (int k = 5; k >= 0; --k) { p[k] = (char)('0' + (int)(fr % 10u)); fr /= 10u; }
+    p += 6;
+    for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
+        *p++ = ' ';
+        const u64 id = ids[q], f = freqs[q];
+        p += put_dec(p, id, dec_digits(id));
+        *p++ = ':';
+        p += put_dec(p, f, dec_digits(f));
+    }
+    *p = '\n';
+}
+
+struct TextEmit {
+    int device = 0;
+    hipStream_t st = nullptr;
+    double* d_terms = nullptr;
+    double* d_logn = nullptr;
+    GrowDev ent, keep, len, off, tmp, misc, exc, rows, val, out;
+    GrowPin h_out, h_rows, h_val;
+    ~TextEmit() {
+        if (d_terms) (void)hipFree(d_terms);
+        if (d_logn) (void)hipFree(d_logn);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+TextEmit* text_emit_create(int device) {
+    if (hipSetDevice(device) != hipSuccess) { (void)fail(DSM_E_HIP, "text emitter: hipSetDevice failed"); return nullptr; }
+    TextEmit* t = new TextEmit();
+    t->device = device;
+    bool ok = hipStreamCreateWithFlags(&t->st, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void**)&t->d_terms, (size_t)TERM_TAB * 8) == hipSuccess && hipMalloc((void**)&t->d_logn, (size_t)LOGN_TAB * 8) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_terms, term_table(), (size_t)TERM_TAB * 8, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_logn, logn_table(), (size_t)LOGN_TAB * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { (void)fail(DSM_E_NOMEM, "text emitter: cannot create the device tables"); delete t; return nullptr; }
+    return t;
+}
+void text_emit_destroy(TextEmit* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    delete t;
+}
+
+#define TE_HIP(x)                                                                     \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) return fail(DSM_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int text_emit_chunk(TextEmit* t, u32 t0, u32 t1, const u32* path_off, const u32* pair_off, const u32* ids, const u64* freqs, const char* paths, u32 d,
+                    double emin, double emax, const char** text, size_t* len, u64* kept_tuples, u64* kept_pairs) {
+    *text = "";
+    *len = 0;
+    if (t1 <= t0) return 0;
+    const u32 nt = t1 - t0;
+    TE_HIP(hipSetDevice(t->device));
+    hipStream_t st = t->st;
+    const u32 exc_cap = 1u << 16;
+    if (int rc = t->ent.ensure((size_t)nt * 8)) return rc;
+    if (int rc = t->keep.ensure(nt)) return rc;
+    if (int rc = t->len.ensure((size_t)nt * 4)) return rc;
+    if (int rc = t->off.ensure(((size_t)nt + 1) * 8)) return rc;
+    if (int rc = t->tmp.ensure((scan_tmp_elems(nt) + 8) * 8)) return rc;
+    if (int rc = t->misc.ensure(64)) return rc;
+    if (int rc = t->exc.ensure((size_t)exc_cap * 4)) return rc;
+    // misc: [0] exceptions, [1] bad value flag, [2..3] pad, then u64 [2] total bytes, [3] kept tuples, [4] kept pairs
+    u32* d_nexc = (u32*)t->misc.p;
+    u32* d_bad = d_nexc + 1;
+    unsigned long long* d_total = (unsigned long long*)t->misc.p + 2;
+    unsigned long long* d_counts = d_total + 1;
+    TE_HIP(hipMemsetAsync(t->misc.p, 0, 64, st));
+    const dim3 grid((nt + 255) / 256);
+    hipLaunchKernelGGL(te_entropy_kernel, grid, dim3(256), 0, st, t0, t1, pair_off, freqs, d, emin, emax, (const double*)t->d_terms, (const double*)t->d_logn,
+                       (double*)t->ent.p, (u8*)t->keep.p, d_nexc, (u32*)t->exc.p, exc_cap);
+    u32 h4[4] = {0, 0, 0, 0};
+    TE_HIP(hipMemcpyAsync(h4, t->misc.p, 16, hipMemcpyDeviceToHost, st));
+    TE_HIP(hipStreamSynchronize(st));
+    const u32 nexc = h4[0];
+    if (nexc > exc_cap) return fail(DSM_E_CAPACITY, "text emitter: more than 65536 tuples of a chunk have frequencies beyond the entropy tables");
+    if (nexc) {  // frequencies of 65536 and more, or a total of 2^20 and more: the host's libm, as emit_job does for the binary batches
+        if (int rc = t->rows.ensure((size_t)nexc * TE_ROW * 8)) return rc;
+        if (int rc = t->val.ensure((size_t)nexc * 8)) return rc;
+        if (int rc = t->h_rows.ensure((size_t)nexc * TE_ROW * 8)) return rc;
+        if (int rc = t->h_val.ensure((size_t)nexc * 8)) return rc;
+        hipLaunchKernelGGL(te_gather_kernel, dim3((nexc + 255) / 256), dim3(256), 0, st, nexc, (const u32*)t->exc.p, pair_off, freqs, (u64*)t->rows.p);
+        TE_HIP(hipMemcpyAsync(t->h_rows.p, t->rows.p, (size_t)nexc * TE_ROW * 8, hipMemcpyDeviceToHost, st));
+        TE_HIP(hipStreamSynchronize(st));
+        const u64* rows = (const u64*)t->h_rows.p;
+        double* val = (double*)t->h_val.p;
+        for (u32 i = 0; i < nexc; ++i) val[i] = exact_entropy(d, rows + (size_t)i * TE_ROW + 1, (u32)rows[(size_t)i * TE_ROW]);
+        TE_HIP(hipMemcpyAsync(t->val.p, val, (size_t)nexc * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(te_scatter_kernel, dim3((nexc + 255) / 256), dim3(256), 0, st, nexc, t0, (const u32*)t->exc.p, (const double*)t->val.p, emin, emax,
+                           (double*)t->ent.p, (u8*)t->keep.p);
+    }
+    hipLaunchKernelGGL(te_len_kernel, grid, dim3(256), 0, st, t0, t1, path_off, pair_off, ids, freqs, (const double*)t->ent.p, (const u8*)t->keep.p, (u32*)t->len.p,
+                       d_counts, d_bad);
+    exclusive_scan<u32, u64>((const u32*)t->len.p, (u64*)t->off.p, nt, (u64*)t->tmp.p, (u64*)d_total, st);
+    u64 h8[8];
+    TE_HIP(hipMemcpyAsync(h8, t->misc.p, 64, hipMemcpyDeviceToHost, st));
+    TE_HIP(hipStreamSynchronize(st));
+    if (((const u32*)h8)[1]) return fail(DSM_E_HIP, "text emitter: an entropy outside the printable range");
+    const u64 total = h8[2];
+    *kept_tuples += h8[3];
+    *kept_pairs += h8[4];
+    if (!total) return 0;
+    if (int rc = t->out.ensure(total + 1)) return rc;
+    if (int rc = t->h_out.ensure(total + 1)) return rc;
+    hipLaunchKernelGGL(te_write_kernel, grid, dim3(256), 0, st, t0, t1, path_off, paths, pair_off, ids, freqs, (const double*)t->ent.p, (const u32*)t->len.p,
+                       (const u64*)t->off.p, (char*)t->out.p);
+    TE_HIP(hipGetLastError());
+    TE_HIP(hipMemcpyAsync(t->h_out.p, t->out.p, total, hipMemcpyDeviceToHost, st));
+    TE_HIP(hipStreamSynchronize(st));
+    *text = (const char*)t->h_out.p;
+    *len = total;
+    return 0;
+}
 
 }  // namespace dsm
 

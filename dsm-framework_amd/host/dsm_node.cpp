@@ -410,7 +410,9 @@ int main(int argc, char** argv) {
         std::vector<const char*> ps;
         for (const std::string& one : pre) ps.push_back(one.c_str());
         dsm_stats st;
-        if (dsm_miner_mine_many(m, ps.data(), (int)ps.size(), to_file, g_out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+        // (the lines are formatted on the card and only the text crosses the bus: dsm_miner_mine_text)
+        auto text_to_file = [](void* ctx, const char* text, size_t len) -> int { return fwrite(text, 1, len, (FILE*)ctx) != len; };
+        if (dsm_miner_mine_text(m, ps.data(), (int)ps.size(), text_to_file, g_out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
         std::cerr << pre.size() << " prefix(es): " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported" << std::endl;
         pre.clear();
     }

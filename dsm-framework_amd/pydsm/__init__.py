@@ -51,6 +51,7 @@ class TupleBatch(C.Structure):
 BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 PREFIX_BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 TUPLE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TupleBatch))
+TEXT_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -148,6 +149,7 @@ def lib():
         L.dsm_formatter_format.argtypes = [C.c_void_p, C.POINTER(TupleBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.dsm_formatter_destroy.argtypes = [C.c_void_p]
         L.dsm_formatter_destroy.restype = None
+        L.dsm_miner_mine_text.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, TEXT_SINK, C.c_void_p, C.POINTER(Stats)]
         L.dsm_free.argtypes = [C.c_void_p]
         L.dsm_index_offload.argtypes = [C.c_void_p]
         L.dsm_index_reload.argtypes = [C.c_void_p, C.c_void_p]
@@ -470,7 +472,35 @@ class Miner:
     def _device(self):
         return int(getattr(self.indexes[0], "device", 0)) if self.indexes else 0
 
+    def mine_text(self, prefixes, on_text=None, on_raw=None):
+        """dsm_miner_mine_text: the reference server's stdout for the prefixes, formatted on the card; on_text(bytes) receives the
+        pieces as they arrive (default: collected and returned); on_raw(address, length) instead sees the library's buffer without
+        a copy (valid during the call only).  -> (bytes or None, Stats)"""
+        out, err = [], []
+
+        def sink(ctx, p, n):
+            try:
+                if on_raw is not None:
+                    on_raw(p, n)
+                    return 0
+                piece = C.string_at(p, n)
+                if on_text is not None:
+                    on_text(piece)
+                else:
+                    out.append(piece)
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+                return 1
+        cb = TEXT_SINK(sink)
+        st = Stats()
+        arr = (C.c_char_p * len(prefixes))(*[p.encode() for p in prefixes])
+        _check_sink(lib().dsm_miner_mine_text(self.h, arr, len(prefixes), cb, None, C.byref(st)), err)
+        return (b"".join(out) if on_text is None and on_raw is None else None), st
+
     def mine(self, prefix, text=True, on_batch=None):
+        if text and on_batch is None and not TEXT_ON_HOST:
+            return self.mine_text([prefix])
         out, err = [], []
         cb = _tuple_sink(out, text, on_batch, err, self._device())
         st = Stats()
@@ -482,6 +512,8 @@ class Miner:
 
     def mine_many(self, prefixes, text=True, on_batch=None):
         """All prefixes in one call (host emission of prefix k overlaps GPU work on prefix k+1)."""
+        if text and on_batch is None and not TEXT_ON_HOST:
+            return self.mine_text(list(prefixes))
         out, err = [], []
         cb = _tuple_sink(out, text, on_batch, err, self._device())
         st = Stats()

@@ -296,6 +296,13 @@ int dsm_miner_mine(dsm_miner* m, const char* prefix, dsm_tuple_sink sink, void* 
  * post-order); the host-side exact-entropy pass of prefix k overlaps the GPU expansion of prefix k+1.  The sink is
  * called from a library thread.  stats are summed over the prefixes. */
 int dsm_miner_mine_many(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_tuple_sink sink, void* ctx, dsm_stats* stats);
+/* The same, with the tuples as the reference server prints them (metaserver.cpp:472-484: "path %f id:freq ...\n"): the sink receives
+ * consecutive pieces of that text, in order, from a library thread.  The exact entropy (metaserver.cpp:366-389, from the host's own
+ * libm tables; frequencies beyond the tables are computed by the host), the emin / emax test, the lines' lengths and the lines are
+ * computed on the card from the tuple arrays; only the text crosses the bus (about 0.6 of the binary batches' bytes).  The bytes are
+ * those of dsm_format_batch over dsm_miner_mine_many's batches. */
+typedef int (*dsm_text_sink)(void* ctx, const char* text, size_t len);
+int dsm_miner_mine_text(dsm_miner* m, const char* const* prefixes, int nprefix, dsm_text_sink sink, void* ctx, dsm_stats* stats);
 int dsm_miner_enumerate(dsm_miner* m, const char* prefix, dsm_byte_sink sink, void* ctx, dsm_stats* stats);
 /* Several prefixes in one call (the reference client walks its prefixes one after the other, one connection each,
  * metaenumerate.cpp:268-309): the sink receives (index of the prefix, bytes, n) for consecutive pieces of that prefix's stream
