@@ -386,7 +386,11 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         Blk16 r0;
         staged_blk(wl, idx0, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, sp, Rsp);  // LF(c, sp-1)
-        const u32 lcode = blk_code_at(r0, (u32)sp & (BLK_SYMS - 1));  // BWT[sp], for the size-1 path
+        // BWT[sp], for the size-1 path.  (A node of frequency 1 exists only when fmin is 1: with fmin >= 2 every node of a level has at
+        // least fmin occurrences, the root all of them -- the test below is then never true and the symbol is not looked up.)
+        const bool may_single = (a.symbol_phase & 1u) && a.fmin <= 1u;
+        u32 lcode = 0;
+        if (may_single) lcode = blk_code_at(r0, (u32)sp & (BLK_SYMS - 1));
         staged_blk(wl, idx1, r0);
         rank4_blk<P, ONESB>(a.sb, sbl, r0, ep1, Rep);  // LF(c, ep)
 #ifdef DSM_LF_SENS_VALU  // sensitivity probe: the two four-base ranks a second time (about 110 vector instructions per tile more)
@@ -428,8 +432,8 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         // What the reference would have spent on this node: two LF per attempted base (Query::pushChar, Query.h:37-45) and two per
         // left-extension interval for every base whose interval is non-empty; BitRank::rank calls = LF calls weighted by the
         // base's code length.  Summed over the wave: (lanes with at least i intervals) x (lanes whose child c is non-empty), as masks.
-        const bool single = (a.symbol_phase & 1u) && sp == ep && live;  // followOneBranch, EnumerateQuery.cpp:105-149
-        if (!__any(single)) {
+        const bool single = may_single && sp == ep && live;  // followOneBranch, EnumerateQuery.cpp:105-149
+        if (!may_single || !__any(single)) {
             const u64 lv = __ballot(live);
             const u64 m1 = __ballot(ne >= 1), m2 = __ballot(ne >= 2);
             u32 s_lf = 0, s_rank = 0;
@@ -647,10 +651,14 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
             expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hA, hB, rn, acc, pplane, &ss, keeptab, cost_pack);
             t0 = t1;
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
+#ifdef DSM_LF_ONE_COPY   // experiment: one copy of the tile's code, the heads moved between the trips
+            hA = hB;
+#else
             if (t0 >= ntile) break;
             expand_tile<P, ONESB, INC, OUTC, SELF, WPB>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, t0, seq, tf, ntile, hB, hA, rn, acc, pplane, &ss, keeptab, cost_pack);
             t0 = t1;
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
+#endif
         }
     }
 #ifdef DSM_CLOCK_PROBE

@@ -26,6 +26,7 @@
 #include <iostream>
 #include <mutex>
 #include <sstream>
+#include <ctime>
 #include <string>
 #include <thread>
 #include <vector>
@@ -412,8 +413,16 @@ int main(int argc, char** argv) {
         dsm_stats st;
         // (the lines are formatted on the card and only the text crosses the bus: dsm_miner_mine_text)
         auto text_to_file = [](void* ctx, const char* text, size_t len) -> int { return fwrite(text, 1, len, (FILE*)ctx) != len; };
-        if (dsm_miner_mine_text(m, ps.data(), (int)ps.size(), text_to_file, g_out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
-        std::cerr << pre.size() << " prefix(es): " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported" << std::endl;
+        const int passes = getenv("DSM_NODE_PASSES") ? atoi(getenv("DSM_NODE_PASSES")) : 1;  // (timing aid: the same prefixes again; the output repeats)
+        for (int pass = 0; pass < passes; ++pass) {
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            if (dsm_miner_mine_text(m, ps.data(), (int)ps.size(), text_to_file, g_out, &st)) { std::cerr << "error: " << dsm_last_error() << std::endl; return 1; }
+            fflush(g_out);
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            std::cerr << pre.size() << " prefix(es): " << st.reported << " nodes, " << st.union_nodes << " paths, " << st.tuples << " reported in "
+                      << (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 << " ms" << std::endl;
+        }
         pre.clear();
     }
     for (const std::string& one : pre) {

@@ -1,4 +1,4 @@
-"""Round-3 roofline evidence.
+"""Roofline evidence of the LF-step kernel (rounds 3 and 4).
   make_traffic.py trace <kernel_trace.csv> STEPS WARMUP
       -> per-pass total of ALL expand_kernel instantiations over the timed passes and the average per REAL launch
          (the launches queued ahead that found another frequency class return at once: they are counted, not averaged in)
@@ -18,10 +18,16 @@ def trace(path, steps, warm):
     passes = steps + warm
     if len(sys.argv) > 5:
         passes += int(sys.argv[5])  # further untimed passes of the profiled command (they come last)
+    if len(dur) % passes != 0:  # every pass issues the same launches: anything else means the command ran something this script does not know
+        raise SystemExit("make_traffic: %d LF-step launches do not divide into %d passes" % (len(dur), passes))
     per = len(dur) // passes
     timed = dur[per * warm: per * (warm + steps)]
-    noop = [d for d in timed if d < 2500]          # a launch that only compares two words: 1.3 us
-    real = [d for d in timed if d >= 2500]
+    # a launch queued ahead that finds another frequency class only compares two words (1.3-2 us); the shortest launch that sweeps a
+    # level -- the root, one tile -- takes 6 us and more: the two kinds are told apart by that gap, checked here
+    noop = [d for d in timed if d < 3500]
+    real = [d for d in timed if d >= 3500]
+    if noop and real and not (max(noop) * 1.5 < min(real)):
+        raise SystemExit("make_traffic: no clear gap between no-op launches (max %d ns) and real ones (min %d ns)" % (max(noop), min(real)))
     out = {"expand_launches_per_pass_total": per, "noop_launches_per_pass": len(noop) / steps, "real_launches_per_pass": len(real) / steps,
            "rocprof_expand_ms_per_step": sum(timed) / steps / 1e6, "rocprof_avg_launch_ms": sum(real) / max(1, len(real)) / 1e6,
            "steps": steps, "warmup": warm}
@@ -52,7 +58,13 @@ def traffic(pmc_path, bench_path, trace_path):
     known = 20.0 * nodes                    # 16-byte compact record + 4-byte handle per node read, coalesced
     per_step = fetch + 0.5 * known + write
     hit, miss = agg.get("TCC_HIT_sum", [0, 0])[0], agg.get("TCC_MISS_sum", [0, 0])[0]
-    out = {"round": 3, "reads": 10000000, "prefix_len": 1, "gpus": 1, "kernel": "expand_kernel<u32,...> (all record-format variants)",
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    h = hashlib.sha256()
+    for f in ("expand.hip", "lfstep.h", "common.h"):
+        h.update(open(os.path.join(root, "dsm-framework_amd", "csrc", f), "rb").read())
+    out = {"round": 4, "kernel_sha16": h.hexdigest()[:16], "reads": 10000000, "prefix_len": 1, "gpus": 1, "kernel": "expand_kernel<u32,...> (all record-format variants)",
            "launches": launches, "FETCH_SIZE_bytes": fetch, "WRITE_SIZE_bytes": write, "coalesced_read_bytes_known": known,
            "correction": "gfx950 FETCH_SIZE counts 128-B coalesced requests at 64 B (calibrated in round 1 with tools/gather_calib: random "
                          "64-B block reads factor 1.00, streaming reads factor 0.50); traffic = FETCH + 0.5*known coalesced reads (16-byte "
@@ -64,7 +76,7 @@ def traffic(pmc_path, bench_path, trace_path):
            "bench_expand_ms_per_step_same_box": bench["detail"]["expand_ms_per_step"],
            "pmc_launches_seen": agg["FETCH_SIZE"][1], "pmc_passes": passes,
            "sq": {k: v[0] for k, v in agg.items() if k.startswith("SQ_")},
-           "source": "tools/profiling/r03_final.sh on one box: bench.py --steps 3 --warmup 1 (JSON line and kernel trace), then one "
+           "source": "tools/profiling/r04_final.sh on one box: bench.py --steps 3 --warmup 1 (JSON line and kernel trace), then one "
                      "rocprofv3 --pmc pass per counter group of bench.py --steps 1 --warmup 0 --no-cpu --no-extras"}
     sq = out["sq"]
     if "SQ_INSTS_VALU" in sq and "SQ_WAVE_CYCLES" in sq and sq["SQ_WAVE_CYCLES"]:
