@@ -22,9 +22,11 @@ constexpr bool LF_DYNAMIC = false;   // round 3's distribution: 256-thread workg
 #else
 constexpr bool LF_DYNAMIC = true;
 #endif
-template <typename P>
+// (INC: the level's records are compact.  The wide levels -- the few at the top of a prefix, a handful of tiles each -- run with two
+// waves per SIMD: their interval-major child loop keeps four children's state in registers.)
+template <typename P, bool INC = true>
 struct LfShape {
-    static constexpr int WAVES_PER_SIMD = sizeof(P) == 4 ? 4 : 3;   // 128 / 168 vector registers
+    static constexpr int WAVES_PER_SIMD = !INC ? 2 : (sizeof(P) == 4 ? 4 : 3);   // 256 / 128 / 168 vector registers
 #ifdef DSM_LF_WPB
     static constexpr int WPB = DSM_LF_WPB;
 #else
@@ -137,8 +139,8 @@ constexpr u32 CREC_WORDS(size_t psize) { return psize == 4 ? 1u : 2u; }  // uint
 template <typename P, bool INC>
 struct RecHead;
 template <typename P>
-struct RecHead<P, false> {   // what a lane needs of its record before anything can be ranked (wide format: decoded fields)
-    P sp, ep, e0min, e0max, e1min, e1max;
+struct RecHead<P, false> {   // what a lane needs of its record before anything can be ranked (wide format: decoded fields, all four slots)
+    P sp, ep, e0min, e0max, e1min, e1max, e2min, e2max, e3min, e3max;
     u32 flags;     // bits 0-3: mask of the non-empty left-extension intervals, bit 8: the node is present in this sample
     u32 r;         // the record's handle (the few nodes with more than two intervals read the others through it)
 };
@@ -157,6 +159,8 @@ __device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap,
     const P sp = rec[rr], ep = rec[cap + rr];
     h.e0min = rec[2 * cap + rr]; h.e0max = rec[3 * cap + rr];
     h.e1min = rec[4 * cap + rr]; h.e1max = rec[5 * cap + rr];
+    h.e2min = rec[6 * cap + rr]; h.e2max = rec[7 * cap + rr];   // (the wide levels are the few at the top of a prefix: their nodes have all
+    h.e3min = rec[8 * cap + rr]; h.e3max = rec[9 * cap + rr];   // four intervals as a rule, and reading them later costs a round trip each)
     const u32 m = reinterpret_cast<const u8*>(rec + (size_t)REC_FIELDS * cap)[rr];
     h.sp = live ? sp : (P)1; h.ep = live ? ep : (P)0;
     h.flags = live ? (m | 0x100u) : 0u;
@@ -173,12 +177,14 @@ __device__ __forceinline__ void load_head(const P* __restrict__ rec, size_t cap,
 template <typename P>
 struct NodeIn {
     P sp, ep, e0min, e0max, e1min, e1max;
+    P e2min = 0, e2max = 0, e3min = 0, e3max = 0;   // wide format only
     u32 emask, r;
     bool live;
 };
 template <typename P>
 __device__ __forceinline__ void decode_head(const RecHead<P, false>& h, NodeIn<P>& n) {
     n.sp = h.sp; n.ep = h.ep; n.e0min = h.e0min; n.e0max = h.e0max; n.e1min = h.e1min; n.e1max = h.e1max;
+    n.e2min = h.e2min; n.e2max = h.e2max; n.e3min = h.e3min; n.e3max = h.e3max;
     n.emask = h.flags & 15u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
 }
 __device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<u32>& n) {
@@ -486,7 +492,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     }
     // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
     bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
-    if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
+    if (!INC) {
+        matches = matches || (ne > 2 && nd.e2min == sp && nd.e2max == ep) || (ne > 3 && nd.e3min == sp && nd.e3max == ep);
+    } else if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
         if (ne > 2) {
 #pragma unroll
             for (int e = 2; e < 4; ++e)
@@ -509,6 +517,79 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     // with the child's base at both ends of the parent's interval (EnumerateQuery.cpp:44-55) -- an end that coincides with sp or
     // ep + 1 is the child's own end -- and the child keeps the interval if it stays non-empty, compacted into its first slots.
     // The ends lie inside [sp, ep + 1], i.e. in one of the two parked blocks unless the interval spans more than two blocks.
+    if constexpr (!INC) {
+        // ---- wide levels (the few at the top of a prefix): interval-major.  Their nodes have up to four children and four intervals
+        // whose ends lie anywhere in a huge interval -- blocks far from the two staged ones.  The pair list below would fetch a block per
+        // (child, interval end) -- up to 32 dependent round trips per node, 300 us per launch for a level of a few thousand nodes, a tenth
+        // of a pass in 36 launches.  Here an interval's two ends are ranked ONCE, for all four bases (two independent block loads issued
+        // together), and every child takes its base's pair of ranks: at most eight loads per node, four rounds.
+        u32 cn4 = 0, cm4 = 0;   // per child: intervals kept so far (3 bits each), their mask (4 bits each)
+        P kl0[4] = {0, 0, 0, 0}, kh0[4] = {0, 0, 0, 0}, kl1[4] = {0, 0, 0, 0}, kh1[4] = {0, 0, 0, 0};  // (compact children only: their first two)
+        const u32 kkpack = bit_list(emask);
+        P prevx = 0, prevR[4] = {0, 0, 0, 0};
+#pragma nounroll
+        for (u32 e = 0; __any(e < ne); ++e) {
+            const bool act = live && e < ne;
+            const u32 kk = (kkpack >> (2 * e)) & 3u;
+            const P xmin = e == 0 ? nd.e0min : (e == 1 ? nd.e1min : (e == 2 ? nd.e2min : nd.e3min));
+            const P xmax = e == 0 ? nd.e0max : (e == 1 ? nd.e1max : (e == 2 ? nd.e2max : nd.e3max));
+            const P xl = act ? xmin : sp, xh = act ? xmax + 1 : ep1;
+            const P bl = xl >> BLK_SHIFT, bh = xh >> BLK_SHIFT;
+            const bool l_sp = xl == sp, l_prev = e > 0 && xl == prevx, h_ep = xh == ep1;
+            const bool l_stag = bl == b0 || bl == b1, h_stag = bh == b0 || bh == b1;
+            const bool farl = act && !l_sp && !l_prev && !l_stag, farh = act && !h_ep && !h_stag;
+            Blk16 Bl, Bh;
+            if (__any(farl || farh)) {  // both requests before either is used
+                load_blk(ix.blk, (u64)(farl ? bl : (P)0), Bl);
+                load_blk(ix.blk, (u64)(farh ? bh : (P)0), Bh);
+                acc.lines += mask_count(__ballot(farl)) + mask_count(__ballot(farh));
+            }
+            P Rl[4], Rh[4];
+            {
+                Blk16 t;
+                staged_blk(wl, bl != b0 ? idx1 : idx0, t);
+                if (farl) t = Bl;
+                rank4_blk<P, ONESB>(a.sb, sbl, t, xl, Rl);
+                staged_blk(wl, bh != b0 ? idx1 : idx0, t);
+                if (farh) t = Bh;
+                rank4_blk<P, ONESB>(a.sb, sbl, t, xh, Rh);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (l_sp) Rl[c] = Rsp[c];
+                if (l_prev) Rl[c] = prevR[c];   // adjacent intervals share an end
+                if (h_ep) Rh[c] = Rep[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const P l = Rl[c], h = Rh[c];
+                if (act && ((present >> c) & 1u) && l <= h - 1) {  // EnumerateQuery.cpp:44-55: the child keeps the interval if it stays non-empty
+                    const u32 cnc = (cn4 >> (3 * c)) & 7u;
+                    if (OUTC && cnc == 0) { kl0[c] = l; kh0[c] = h - 1; }
+                    else if (OUTC && cnc == 1) { kl1[c] = l; kh1[c] = h - 1; }
+                    else { out[(size_t)(2 + 2 * cnc) * cap + qa[c]] = l; out[(size_t)(3 + 2 * cnc) * cap + qa[c]] = h - 1; }
+                    cn4 += 1u << (3 * c);
+                    cm4 |= 1u << (4 * c + kk);
+                }
+                prevR[c] = Rh[c];
+            }
+            prevx = xh;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((present >> c) & 1u) {
+                const u32 cnc = (cn4 >> (3 * c)) & 7u, cmc = (cm4 >> (4 * c)) & 15u;
+                if (OUTC) store_child<P, true>(out, cap, qa[c], Rsp[c], Rep[c] - 1, kl0[c], kh0[c], kl1[c], kh1[c], cnc, cmc);
+                else {
+                    out[qa[c]] = Rsp[c];
+                    out[cap + qa[c]] = Rep[c] - 1;
+                    reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[qa[c]] = (u8)cmc;
+                }
+                if (!OUTC) acc.rb_lane += (cnc < 2 ? cnc : 2u) * 2u * (u32)sizeof(P);
+                if (cnc > 2) acc.rb_lane += (cnc - 2) * 2u * (u32)sizeof(P);
+            }
+        }
+    } else
     {
         const u32 ne1 = ne ? ne : 1u;
         const u32 npair = k * ne1;
@@ -600,7 +681,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
                                              P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                              u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
                                              unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane) {
-    constexpr int WPB = LfShape<P>::WPB;
+    constexpr int WPB = LfShape<P, INC>::WPB;
     uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
     if (!ONESB) {
         const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
@@ -690,11 +771,11 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
 
 // (32-bit positions fit four waves per SIMD without spilling when the allocator is told to aim for it; 64-bit positions take three)
 template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(LfShape<P>::WPB * 64) __attribute__((amdgpu_waves_per_eu(LfShape<P>::WAVES_PER_SIMD)))
+__global__ __launch_bounds__((LfShape<P, INC>::WPB * 64)) __attribute__((amdgpu_waves_per_eu((LfShape<P, INC>::WAVES_PER_SIMD))))
 void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict__ rec, P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt,
                    P* __restrict__ valf, u8* __restrict__ pl, ExpandArgs a, u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
-    __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
+    __shared__ uint4 parked[LfShape<P, INC>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
     if (a.dyn) {  // (uniform over the grid: every block takes the same way out)
         const u32 F = a.dyn[0], cls = a.dyn[1];
@@ -708,10 +789,10 @@ void expand_kernel(DevIndex ix, const u32* __restrict__ rp, const P* __restrict_
 }
 
 template <typename P, bool ONESB, bool INC, bool OUTC>
-__global__ __launch_bounds__(LfShape<P>::WPB * 64) __attribute__((amdgpu_waves_per_eu(LfShape<P>::WAVES_PER_SIMD)))
+__global__ __launch_bounds__((LfShape<P, INC>::WPB * 64)) __attribute__((amdgpu_waves_per_eu((LfShape<P, INC>::WAVES_PER_SIMD))))
 void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
     __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
-    __shared__ uint4 parked[LfShape<P>::WPB * WAVE_LDS_WORDS];
+    __shared__ uint4 parked[LfShape<P, INC>::WPB * WAVE_LDS_WORDS];
     __shared__ u32 tile_ctr;
     const ExpandSample& S = b.s[blockIdx.y];
     a.sb = S.sb;
@@ -743,12 +824,12 @@ int lf_step_geometry(bool wide_pos, int device, LfGeometry* g) { return wide_pos
 template <typename P, bool SB, bool IC, bool OC>
 static void launch1(dim3 grid, hipStream_t st, const DevIndex& ix, const u32* rp, const void* rec, void* out, u64* splane, u32* cnt, void* valf, u8* pl,
                     const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
-    hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P>::WPB * 64), 0, st, ix, rp, (const P*)rec, (P*)out, splane, cnt, (P*)valf, pl, a, counters,
+    hipLaunchKernelGGL((expand_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P, IC>::WPB * 64), 0, st, ix, rp, (const P*)rec, (P*)out, splane, cnt, (P*)valf, pl, a, counters,
                        childmax);
 }
 template <typename P, bool SB, bool IC, bool OC>
 static void launchb(dim3 grid, hipStream_t st, const ExpandBatch& b, const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
-    hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P>::WPB * 64), 0, st, b, a, counters, childmax);
+    hipLaunchKernelGGL((expand_batch_kernel<P, SB, IC, OC>), grid, dim3(LfShape<P, IC>::WPB * 64), 0, st, b, a, counters, childmax);
 }
 // (the formats are template parameters: eight instantiations per position type)
 #define DSM_LF_DISPATCH(FN, P, ...)                                                             \
@@ -768,7 +849,8 @@ static void launchb(dim3 grid, hipStream_t st, const ExpandBatch& b, const Expan
 
 void lf_step_launch(const LfConfig& c, const LfGeometry& g, u64 tiles_bound, hipStream_t st, const DevIndex& ix, const u32* rp, const void* rec, void* out,
                     u64* splane, u32* cnt, void* valf, u8* pl, const ExpandArgs& a, u64* counters, unsigned long long* childmax) {
-    u64 need = (tiles_bound + g.waves_per_block - 1) / g.waves_per_block;  // workgroups that get a tile at all
+    const u32 wpb = c.fmt_in ? g.waves_per_block : (u32)(c.wide_pos ? LfShape<u64, false>::WPB : LfShape<u32, false>::WPB);  // (wide levels: smaller workgroups)
+    u64 need = (tiles_bound + wpb - 1) / wpb;  // workgroups that get a tile at all
     if (need < 1) need = 1;
     const dim3 grid((u32)(need < g.blocks ? need : g.blocks));
     if (c.wide_pos) DSM_LF_DISPATCH(launch1, u64, grid, st, ix, rp, rec, out, splane, cnt, valf, pl, a, counters, childmax);
@@ -782,7 +864,8 @@ void lf_step_launch_batch(const LfConfig& c, const LfGeometry& g, u32 grid_facto
     // workgroup is another start-up, and a workgroup's waves balance their tiles among themselves anyway); round 3's workgroups of four
     // waves wanted 8 (972 ms).
     const u32 ntile = (a.F + 63) >> 6;
-    u32 need = (ntile + g.waves_per_block - 1) / g.waves_per_block;
+    const u32 wpb = c.fmt_in ? g.waves_per_block : (u32)(c.wide_pos ? LfShape<u64, false>::WPB : LfShape<u32, false>::WPB);
+    u32 need = (ntile + wpb - 1) / wpb;
     if (need < 1) need = 1;
     u32 gx = (grid_factor ? grid_factor : 1u) * g.blocks / (u32)nb;
     if (gx < 1) gx = 1;

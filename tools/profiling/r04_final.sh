@@ -3,7 +3,7 @@
 # trace domains -- one pass per counter group).
 # Writes gpurun_out/r04_*; tools/profiling/make_traffic.py turns them into profiles/traffic.json.
 set -eu
-: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}"
+: "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT is the root of the snapshot}"
 R="$GRAFT_REPO_ROOT"
 O="$R/gpurun_out"
 mkdir -p "$O"
