@@ -2720,6 +2720,7 @@ class Engine {
             }
             DSM_HIP(hipGetLastError());
             if (trace_levels) fprintf(stderr, "dsm level prefix=%s depth=%u F=%u\n", prefix.c_str(), depth, F);
+            if (pend.submit && (F >= 200000u || depth >= 24)) { if (int rc = flush_pending()) return rc; }  // the previous prefix's tuples may leave now
             stats.union_nodes += depth >= 1 ? F : 0;
             if (F > stats.max_frontier) stats.max_frontier = F;
             ++stats.levels;
@@ -2732,6 +2733,7 @@ class Engine {
             if (L.size() > 60000) return fail(DSM_E_CAPACITY, "trie deeper than 60000 levels");
         }
         const u32 nlev = (u32)L.size();  // levels 0..nlev-1, level l holds the nodes of depth l
+        if (int rc = flush_pending()) return rc;  // (a prefix that never got wide or deep)
 
         bool ready = false;
         if (stream_mode) {
@@ -2761,7 +2763,10 @@ class Engine {
                 if (int rc = agree_min(ok, &all_ok)) return rc;
                 if (!all_ok) return fail(DSM_E_CAPACITY, "device arena exhausted on a rank: use a longer prefix or a larger arena_bytes");
             }
-            if (ready) emitter.submit();
+            if (ready) pend.submit = true;   // (the set is prepared; flush_pending hands it over once the next prefix is under way)
+            else pend.E = nullptr;
+            static const bool defer = !(getenv("DSM_DEFER_EMIT") && atoi(getenv("DSM_DEFER_EMIT")) == 0);  // (0: at once, for A/B runs)
+            if (!defer) { if (int rc = flush_pending()) return rc; }
         }
 
         DSM_HIP(hipEventRecord(ev1, st));
@@ -2945,20 +2950,54 @@ class Engine {
         // keeps the ones of its chunk), so that a chunk is on its way to the host while the next one is being filled -- what shows at
         // the end of a pass, where nothing else hides the last prefix's copy (1 GB, 20 ms, behind a 14 ms fill).
         if (!copy_stream) DSM_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        for (int c = 0; c < cbs.n; ++c) {  // fill, copy and signal chunk by chunk
+        // The fills go out now.  The copies to the host -- blit kernels that spread over the compute units and stay for the length of a PCIe
+        // transfer -- and the emitter's work are HELD BACK until the next prefix is a few levels deep (flush_pending): the first levels of
+        // a prefix are a dozen dependent launches of a workgroup or two each, and beside the previous prefix's copies every one of them
+        // waited for a compute unit (measured: 300-1500 us for a one-workgroup LF-step launch that takes 10 us alone; 9 ms per pass).
+        for (int c = 0; c < cbs.n; ++c) {
             const u32 t0 = cbs.tb[c], t1 = cbs.tb[c + 1];
             hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs, t0, t1);
             DSM_HIP(hipGetLastError());
             E.cb[c] = t0; E.cb[c + 1] = t1;
             if (!E.cready[c]) DSM_HIP(hipEventCreateWithFlags(&E.cready[c], hipEventDisableTiming));
-            if (text_mode) {  // the emitter thread takes the chunk from here, on its own stream
-                DSM_HIP(hipEventRecord(E.cready[c], st));
-                continue;
-            }
             if (!chunk_filled[c]) DSM_HIP(hipEventCreateWithFlags(&chunk_filled[c], hipEventDisableTiming));
             DSM_HIP(hipEventRecord(chunk_filled[c], st));
+            pend.off[2 * c] = h_totals[16 + 2 * c]; pend.off[2 * c + 1] = h_totals[17 + 2 * c];
+        }
+        pend.off[2 * cbs.n] = h_totals[16 + 2 * cbs.n]; pend.off[2 * cbs.n + 1] = h_totals[17 + 2 * cbs.n];
+        pend.E = &E; pend.nchunk = cbs.n; pend.text = text_mode;
+        E.nt = nt;
+        emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
+        *ready = true;
+        return 0;
+    }
+    // what finish_mine held back (see there): the chunks' copies, then the emitter
+    struct PendingEmit {
+        EmitSet* E = nullptr;
+        int nchunk = 0;
+        bool text = false, submit = false;
+        u64 off[2 * (EmitSet::MAX_CHUNKS + 1)];  // path / pair offsets of the chunk boundaries
+    } pend;
+    int flush_pending() {
+        if (!pend.E || !pend.submit) return 0;
+        EmitSet& E = *pend.E;
+        pend.E = nullptr;
+        pend.submit = false;
+        DSM_HIP(hipSetDevice(device));
+        const u32* path_off = (const u32*)E.dev[0].p;
+        const u32* pair_off = (const u32*)E.dev[1].p;
+        const u32* d_ids = (const u32*)E.dev[2].p;
+        const u64* d_freqs = (const u64*)E.dev[3].p;
+        const char* d_paths = (const char*)E.dev[4].p;
+        for (int c = 0; c < pend.nchunk; ++c) {
+            const u32 t0 = E.cb[c], t1 = E.cb[c + 1];
+            if (pend.text) {  // the emitter thread takes the chunk from the card, on its own stream
+                DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
+                DSM_HIP(hipEventRecord(E.cready[c], copy_stream));
+                continue;
+            }
             DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
-            const u64 pb0 = h_totals[16 + 2 * c], qb0 = h_totals[17 + 2 * c], pb1 = h_totals[16 + 2 * (c + 1)], qb1 = h_totals[17 + 2 * (c + 1)];
+            const u64 pb0 = pend.off[2 * c], qb0 = pend.off[2 * c + 1], pb1 = pend.off[2 * (c + 1)], qb1 = pend.off[2 * (c + 1) + 1];
             // boundary entries are shared by neighbouring chunks: both copy the same value
             DSM_HIP(hipMemcpyAsync((u32*)E.pin[0].p + t0, path_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
             DSM_HIP(hipMemcpyAsync((u32*)E.pin[1].p + t0, pair_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
@@ -2970,9 +3009,7 @@ class Engine {
             DSM_HIP(hipEventRecord(E.cready[c], copy_stream));
         }
         DSM_HIP(hipEventRecord(E.ready, copy_stream));
-        E.nt = nt;
-        emitter.d = d; emitter.emin = prm.emin; emitter.emax = prm.emax; emitter.sink = sink; emitter.ctx = ctx;
-        *ready = true;
+        emitter.submit();
         return 0;
     }
     hipStream_t copy_stream = nullptr;
@@ -2981,6 +3018,7 @@ class Engine {
 
     // wait for the emitter and fold its counters into stats
     int finish_emits() {
+        if (int rc = flush_pending()) return rc;
         emitter.drain();
         std::lock_guard<std::mutex> lk(emitter.mu);
         stats.tuples += emitter.tuples; stats.pairs += emitter.pairs; stats.host_ms += emitter.ms;

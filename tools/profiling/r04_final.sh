@@ -13,7 +13,8 @@ echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/r04_prof" -- python3 "$R/bench.py" --steps $STEPS --warmup $WARM --no-cpu --no-extras > "$O/r04_prof.log" 2>&1
 cp "$(find "$O/r04_prof" -name "*kernel_stats.csv" | head -1)" "$O/r04_kernel_stats.csv"
-python3 "$R/tools/profiling/make_traffic.py" trace "$(find "$O/r04_prof" -name "*kernel_trace.csv" | head -1)" $STEPS $WARM > "$O/r04_trace_summary.json"
+REAL=$(python3 -c "import json,sys; j=json.loads([l for l in open('$O/r04_bench.json') if l.startswith('{')][-1]); print(j['roofline']['launches'] // j['steps'])")
+python3 "$R/tools/profiling/make_traffic.py" trace "$(find "$O/r04_prof" -name "*kernel_trace.csv" | head -1)" $STEPS $WARM 0 $REAL > "$O/r04_trace_summary.json"
 find "$O/r04_prof" -name "*.csv" -size +1M -delete
 echo "stats done"
 rm -f "$O/r04_pmc.txt"
