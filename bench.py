@@ -54,10 +54,11 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="independent prefix lanes (own stream, own communicator) that overlap one lane's "
                     "all-gather with the other's kernels; default 1 (N=1) / 2 (N>1)")
     ap.add_argument("--nlocal", type=int, default=1, help="samples per GPU (BASELINE configs[4]: 8 per GPU); default 1")
-    ap.add_argument("--exchange", choices=["allgather", "owner"], default=os.environ.get("DSM_BENCH_MODE", "allgather"),
+    ap.add_argument("--exchange", choices=["allgather", "owner", "both"], default=os.environ.get("DSM_BENCH_MODE", "allgather"),
                     help="N > 1: 'allgather' = every rank merges every prefix from one all-gather per level; 'owner' = the reference's "
                          "partition, prefix k is merged by rank k %% N alone (columns gathered to it, the union's child masks broadcast "
-                         "back), one lane per owner so that every rank is the server of one lane and a client in the others")
+                         "back), one lane per owner so that every rank is the server of one lane and a client in the others; 'both' = one "
+                         "after the other on the same indexes, both values in the line, the faster one as the headline")
     ap.add_argument("--workdir", default=os.environ.get("DSM_BENCH_DIR", "/tmp/dsm_bench"))
     return ap.parse_args()
 
@@ -452,183 +453,211 @@ def main():
     # One-letter prefixes at every N: a level costs a fixed ~50 us of launches (plus one all-gather when N > 1), and 16
     # two-letter prefixes have four times the levels (measured at N=1: 290 vs 353 ms per pass).  With more ranks than
     # prefixes some ranks emit nothing; that costs less than the extra levels.
-    owner_mode = args.exchange == "owner" and (world > 1 or forced)
-    # owner mode wants at least as many prefixes as ranks (every rank the server of some prefix): two letters beyond four ranks
-    plen = args.prefix_len if args.prefix_len >= 0 else (2 if owner_mode and world > 4 else 1)
-    prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
-    pmin = args.pmin if args.pmin > 0 else (1 if world * args.nlocal == 1 else 2)
+    def run_mode(mode):
+        """one measurement (lanes, miners, warm-up, K timed steps) with the given exchange; the miners stay open (the caller closes them)"""
+        owner_mode = mode == "owner" and (world > 1 or forced)
+        # owner mode wants at least as many prefixes as ranks (every rank the server of some prefix): two letters beyond four ranks
+        plen = args.prefix_len if args.prefix_len >= 0 else (2 if owner_mode and world > 4 else 1)
+        prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]
+        pmin = args.pmin if args.pmin > 0 else (1 if world * args.nlocal == 1 else 2)
 
-    # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
-    # one collective per frontier level, nothing else on the data path.  A lane = one miner with its own HIP stream and
-    # (multi-rank) its own communicator; lanes take the prefixes round-robin and run concurrently, so one lane's
-    # collective overlaps the other lane's kernels.
-    # Multi-rank runs use two lanes so that one lane's all-gather overlaps the other lane's kernels.  Both lanes use the ONE
-    # default communicator; pydsm.dist.TurnGate makes them enqueue their collectives in strict alternation, i.e. in the same
-    # order on every rank (each lane issues the same number of collectives everywhere because every rank walks the same
-    # union trie).  DSM_BENCH_LANES / --lanes override.
-    nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 and not forced else "2"))
-    if owner_mode:
-        nlanes = world  # lane j: the prefixes rank j serves
-    nlanes = max(1, min(nlanes, len(prefixes))) if not owner_mode else nlanes
-    lanes = []
-    gate = None
-    # The exchange itself: by default the library's own (dsm_rccl_*: one RCCL communicator per lane, ncclAllGather from the C
-    # callback on the lane's stream, no Python per level; torch.distributed only carries the ids and the timing barrier).
-    # DSM_BENCH_EXCHANGE=torch (and every non-nccl backend, e.g. gloo rehearsals with several ranks on one card) goes through
-    # pydsm.dist.Exchange = torch.distributed.all_gather_into_tensor from a Python callback.
-    native = (world > 1 or forced) and dist.get_backend() == "nccl" and os.environ.get("DSM_BENCH_EXCHANGE", "rccl") == "rccl"
-    if (world > 1 or forced) and nlanes > 1:
-        if native:
-            gate = pydsm.RcclGate(nlanes)
-        else:
-            from pydsm.dist import TurnGate
-            gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
-    for j in range(nlanes):
-        lane = {"prefixes": prefixes[j::nlanes], "stream": torch.cuda.Stream(device=dev) if nlanes > 1 else torch.cuda.current_stream()}
-        allgather = exchange = None
-        if native:
-            try:
-                ids = [pydsm.RcclComm.unique_id() if rank == 0 else None]
-            except pydsm.DsmError as e:  # librccl could not be loaded: the same on every rank of a node
-                ids = [None]
-                print("bench.py: native exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            if ids[0] is None:
-                native = False
-                if gate is not None:
-                    from pydsm.dist import TurnGate
-                    gate = TurnGate(nlanes)
-            else:
-                lane["rccl"] = pydsm.RcclComm(ids[0], world, rank, local)  # collective over the ranks
-                allgather = lane["rccl"]
-        if native:
-            pass
-        elif world > 1 or forced:
-            from pydsm.dist import Exchange
-            group = None  # the default communicator, shared by the lanes
-            lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
-            allgather, exchange = lane["ex"].allgather, lane["ex"].params()
-        arena = 0
-        if nlanes > 1:  # split what is left between the lanes still to be created (and the ranks sharing this card)
-            free_b, _ = torch.cuda.mem_get_info(dev)
-            sharing = (world + ndev - 1) // max(1, ndev)
-            want = (256 << 20) + 64 * sum(x.n for x in ixs) * world
-            arena = int(min(want, free_b * 0.7 / (nlanes - j) / sharing))
-        lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
-                                    allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
-                                    emit_owner_only=world > 1 or forced, arena_bytes=arena, wide=1 if args.wide else 0,
-                                    stream_mode=args.stream_mode, owner_rank=j if owner_mode else None,
-                                    owner_exchange=(lane.get("rccl") or lane.get("ex")) if owner_mode else None)
-        lanes.append(lane)
-    if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
-        for j, ln in enumerate(lanes):
+        # exchange buffers owned by torch so that torch.distributed (RCCL over xGMI) all-gathers them device to device:
+        # one collective per frontier level, nothing else on the data path.  A lane = one miner with its own HIP stream and
+        # (multi-rank) its own communicator; lanes take the prefixes round-robin and run concurrently, so one lane's
+        # collective overlaps the other lane's kernels.
+        # Multi-rank runs use two lanes so that one lane's all-gather overlaps the other lane's kernels.  Both lanes use the ONE
+        # default communicator; pydsm.dist.TurnGate makes them enqueue their collectives in strict alternation, i.e. in the same
+        # order on every rank (each lane issues the same number of collectives everywhere because every rank walks the same
+        # union trie).  DSM_BENCH_LANES / --lanes override.
+        nlanes = args.lanes if args.lanes > 0 else int(os.environ.get("DSM_BENCH_LANES", "1" if world == 1 and not forced else "2"))
+        if owner_mode:
+            nlanes = world  # lane j: the prefixes rank j serves
+        nlanes = max(1, min(nlanes, len(prefixes))) if not owner_mode else nlanes
+        lanes = []
+        gate = None
+        # The exchange itself: by default the library's own (dsm_rccl_*: one RCCL communicator per lane, ncclAllGather from the C
+        # callback on the lane's stream, no Python per level; torch.distributed only carries the ids and the timing barrier).
+        # DSM_BENCH_EXCHANGE=torch (and every non-nccl backend, e.g. gloo rehearsals with several ranks on one card) goes through
+        # pydsm.dist.Exchange = torch.distributed.all_gather_into_tensor from a Python callback.
+        native = (world > 1 or forced) and dist.get_backend() == "nccl" and os.environ.get("DSM_BENCH_EXCHANGE", "rccl") == "rccl"
+        if (world > 1 or forced) and nlanes > 1:
             if native:
-                ln["rccl"].attach_gate(gate, j)
+                gate = pydsm.RcclGate(nlanes)
             else:
-                ln["ex"].gate = gate
-
-    tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
-           "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0,
-           "xsent": 0, "xrecv": 0}
-    import threading
-    tot_lock = threading.Lock()
-
-    def lane_step(lane, record, errs):
-        try:
-            if gate is not None:
-                gate.begin(lanes.index(lane))
-            with torch.cuda.stream(lane["stream"]):
-                if args.stream_mode:
-                    nbs, st = lane["miner"].enumerate_many(lane["prefixes"], discard=True)
-                    tot["wire_bytes"] = tot.get("wire_bytes", 0) + (sum(nbs) if record else 0)
+                from pydsm.dist import TurnGate
+                gate = TurnGate(nlanes)  # same enqueue order of the lanes' collectives on every rank
+        for j in range(nlanes):
+            lane = {"prefixes": prefixes[j::nlanes], "stream": torch.cuda.Stream(device=dev) if nlanes > 1 else torch.cuda.current_stream()}
+            allgather = exchange = None
+            if native:
+                try:
+                    ids = [pydsm.RcclComm.unique_id() if rank == 0 else None]
+                except pydsm.DsmError as e:  # librccl could not be loaded: the same on every rank of a node
+                    ids = [None]
+                    print("bench.py: native exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+                if world > 1:
+                    dist.broadcast_object_list(ids, src=0)
+                if ids[0] is None:
+                    native = False
+                    if gate is not None:
+                        from pydsm.dist import TurnGate
+                        gate = TurnGate(nlanes)
                 else:
-                    st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
-            if record:
-                with tot_lock:
-                    tot["reported"] += st.reported
-                    tot["rank_ops"] += st.rank_ops
-                    tot["lf_steps"] += st.lf_steps
-                    tot["expand_ms"] += st.expand_ms
-                    tot["launches"] += st.expand_launches
-                    tot["tuples"] += st.tuples
-                    tot["union"] += st.union_nodes
-                    tot["device_ms"] += st.device_ms
-                    tot["host_ms"] += st.host_ms
-                    tot["cand"] += st.candidates
-                    tot["index_lines"] += st.index_lines
-                    tot["records_read"] += st.records_read
-                    tot["record_bytes"] += st.record_bytes
-                    tot["slots"] += st.expand_slots
-                    tot["colbytes"] += st.expand_column_bytes
-                    tot["xsent"] += st.exchange_bytes_sent
-                    tot["xrecv"] += st.exchange_bytes_received
-                    tot["splits"] = tot.get("splits", 0) + st.splits
-                    tot["levels"] = tot.get("levels", 0) + st.levels
-                    tot["max_frontier"] = max(tot.get("max_frontier", 0), st.max_frontier)
-        except Exception as e:  # noqa: BLE001
-            errs.append(e)
-            if world > 1:  # the other ranks are blocked in a collective: fail the whole job instead of hanging it
-                import traceback
-                traceback.print_exc()
-                sys.stderr.flush()
-                os._exit(13)
-        finally:
+                    lane["rccl"] = pydsm.RcclComm(ids[0], world, rank, local)  # collective over the ranks
+                    allgather = lane["rccl"]
+            if native:
+                pass
+            elif world > 1 or forced:
+                from pydsm.dist import Exchange
+                group = None  # the default communicator, shared by the lanes
+                lane["ex"] = Exchange(int(os.environ.get("DSM_BENCH_XBYTES", str(1 << 30))) // nlanes, world, dev, group=group, stream=lane["stream"], lane=j)
+                allgather, exchange = lane["ex"].allgather, lane["ex"].params()
+            arena = 0
+            if nlanes > 1:  # split what is left between the lanes still to be created (and the ranks sharing this card)
+                free_b, _ = torch.cuda.mem_get_info(dev)
+                sharing = (world + ndev - 1) // max(1, ndev)
+                want = (256 << 20) + 64 * sum(x.n for x in ixs) * world
+                arena = int(min(want, free_b * 0.7 / (nlanes - j) / sharing))
+            lane["miner"] = pydsm.Miner(ixs, fmin=args.fmin, pmin=pmin, pmax=args.pmax, emax=args.emax, world_size=world, rank=rank,
+                                        allgather=allgather, exchange=exchange, stream=lane["stream"].cuda_stream,
+                                        emit_owner_only=world > 1 or forced, arena_bytes=arena, wide=1 if args.wide else 0,
+                                        stream_mode=args.stream_mode, owner_rank=j if owner_mode else None,
+                                        owner_exchange=(lane.get("rccl") or lane.get("ex")) if owner_mode else None)
+            lanes.append(lane)
+        if gate is not None:  # creation-time collectives ran lane by lane on the main thread; from here on lanes take turns
+            for j, ln in enumerate(lanes):
+                if native:
+                    ln["rccl"].attach_gate(gate, j)
+                else:
+                    ln["ex"].gate = gate
+
+        tot = {"reported": 0, "rank_ops": 0, "lf_steps": 0, "expand_ms": 0.0, "launches": 0, "tuples": 0, "union": 0,
+               "device_ms": 0.0, "host_ms": 0.0, "cand": 0, "index_lines": 0, "records_read": 0, "record_bytes": 0, "slots": 0, "colbytes": 0,
+               "xsent": 0, "xrecv": 0}
+        import threading
+        tot_lock = threading.Lock()
+
+        def lane_step(lane, record, errs):
+            try:
+                if gate is not None:
+                    gate.begin(lanes.index(lane))
+                with torch.cuda.stream(lane["stream"]):
+                    if args.stream_mode:
+                        nbs, st = lane["miner"].enumerate_many(lane["prefixes"], discard=True)
+                        tot["wire_bytes"] = tot.get("wire_bytes", 0) + (sum(nbs) if record else 0)
+                    else:
+                        st = lane["miner"].mine_many(lane["prefixes"], text=False)[1]
+                if record:
+                    with tot_lock:
+                        tot["reported"] += st.reported
+                        tot["rank_ops"] += st.rank_ops
+                        tot["lf_steps"] += st.lf_steps
+                        tot["expand_ms"] += st.expand_ms
+                        tot["launches"] += st.expand_launches
+                        tot["tuples"] += st.tuples
+                        tot["union"] += st.union_nodes
+                        tot["device_ms"] += st.device_ms
+                        tot["host_ms"] += st.host_ms
+                        tot["cand"] += st.candidates
+                        tot["index_lines"] += st.index_lines
+                        tot["records_read"] += st.records_read
+                        tot["record_bytes"] += st.record_bytes
+                        tot["slots"] += st.expand_slots
+                        tot["colbytes"] += st.expand_column_bytes
+                        tot["xsent"] += st.exchange_bytes_sent
+                        tot["xrecv"] += st.exchange_bytes_received
+                        tot["splits"] = tot.get("splits", 0) + st.splits
+                        tot["levels"] = tot.get("levels", 0) + st.levels
+                        tot["max_frontier"] = max(tot.get("max_frontier", 0), st.max_frontier)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+                if world > 1:  # the other ranks are blocked in a collective: fail the whole job instead of hanging it
+                    import traceback
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    os._exit(13)
+            finally:
+                if gate is not None:
+                    gate.retire(lanes.index(lane))
+
+        def step(record):
+            errs = []
             if gate is not None:
-                gate.retire(lanes.index(lane))
+                gate.reset()
+            if len(lanes) == 1:
+                lane_step(lanes[0], record, errs)
+            else:
+                ths = [threading.Thread(target=lane_step, args=(ln, record, errs)) for ln in lanes]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            if errs:
+                raise errs[0]
 
-    def step(record):
-        errs = []
-        if gate is not None:
-            gate.reset()
-        if len(lanes) == 1:
-            lane_step(lanes[0], record, errs)
-        else:
-            ths = [threading.Thread(target=lane_step, args=(ln, record, errs)) for ln in lanes]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        if errs:
-            raise errs[0]
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def barrier():
+        if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and gate is not None and not native:
+            def dump_order():
+                with open(os.path.join(ROOT, "gpurun_out", "order_rank%d.txt" % rank), "w") as f:
+                    for it in gate.log:
+                        f.write("%d %d\n" % it)
+            import atexit
+            atexit.register(dump_order)
+            import threading as _th
+            _t = _th.Timer(100, dump_order)
+            _t.daemon = True
+            _t.start()
+        if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and not native:
+            import atexit
+            atexit.register(lambda: print("TRACE rank %d: %s" % (rank, lanes[0]["ex"].trace[:60]), file=sys.stderr, flush=True))
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt, float(tot["reported"])], dtype=torch.float64, device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone()
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dt = float(tmax[0])
+            reported_all = float(tsum[1])
+        else:
+            reported_all = float(tot["reported"])
+        return {"owner_mode": owner_mode, "plen": plen, "prefixes": prefixes, "pmin": pmin, "nlanes": nlanes, "lanes": lanes, "native": native,
+                "tot": tot, "dt": dt, "reported_all": reported_all, "mode": mode}
 
-    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and gate is not None and not native:
-        def dump_order():
-            with open(os.path.join(ROOT, "gpurun_out", "order_rank%d.txt" % rank), "w") as f:
-                for it in gate.log:
-                    f.write("%d %d\n" % it)
-        import atexit
-        atexit.register(dump_order)
-        import threading as _th
-        _t = _th.Timer(100, dump_order)
-        _t.daemon = True
-        _t.start()
-    if os.environ.get("DSM_TRACE_EXCHANGE") and world > 1 and not native:
-        import atexit
-        atexit.register(lambda: print("TRACE rank %d: %s" % (rank, lanes[0]["ex"].trace[:60]), file=sys.stderr, flush=True))
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(tot["reported"])], dtype=torch.float64, device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
-    if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-        reported_all = float(tsum[1])
+    # --exchange both (N > 1): the all-gather and the owner partition on the same indexes, one after the other; the line reports both and
+    # carries the faster one as its value -- the first run on a multi-GPU node then says which partition to keep
+    both = None
+    if args.exchange == "both" and (world > 1 or forced):
+        ra = run_mode("allgather")
+        for ln in ra["lanes"]:
+            ln["miner"].close()
+        rb = run_mode("owner")
+        va, vb = ra["reported_all"] / ra["dt"], rb["reported_all"] / rb["dt"]
+        both = {"allgather": {"value": va, "ms_per_step": ra["dt"] * 1e3 / args.steps, "exchange_bytes_sent_per_step_rank0": ra["tot"]["xsent"] / max(1, args.steps),
+                              "exchange_bytes_received_per_step_rank0": ra["tot"]["xrecv"] / max(1, args.steps), "lanes": ra["nlanes"],
+                              "collectives_per_step_rank0": ra["tot"].get("levels", 0) / max(1, args.steps)},
+                "owner": {"value": vb, "ms_per_step": rb["dt"] * 1e3 / args.steps, "exchange_bytes_sent_per_step_rank0": rb["tot"]["xsent"] / max(1, args.steps),
+                          "exchange_bytes_received_per_step_rank0": rb["tot"]["xrecv"] / max(1, args.steps), "lanes": rb["nlanes"],
+                          "collectives_per_step_rank0": 2 * rb["tot"].get("levels", 0) / max(1, args.steps)}}
+        both["headline"] = "allgather" if va > vb else "owner"
+        res = ra if va > vb else rb   # the line describes the faster mode
+        open_lanes = rb["lanes"]      # (the owner run's miners are the ones still open)
     else:
-        reported_all = float(tot["reported"])
+        res = run_mode("owner" if args.exchange == "owner" else "allgather")
+        open_lanes = res["lanes"]
+    owner_mode, plen, prefixes, pmin, nlanes, lanes, native = (res[k] for k in ("owner_mode", "plen", "prefixes", "pmin", "nlanes", "lanes", "native"))
+    tot, dt, reported_all = res["tot"], res["dt"], res["reported_all"]
     # Text (metaserver.cpp:472-484's printf loop) is outside the timed region of `value` (the sink receives binary batches).  One more
     # pass with a sink that formats every batch on the GPU (dsm_formatter_format, the drop-in's way since round 4), timed twice: the
     # calls alone (`format_ms_per_step`) and the whole pass (`text_pass_ms`: what a user of the text surface waits for; the formatter's
@@ -690,7 +719,7 @@ def main():
             text_pass_ms = (time.perf_counter() - t1) * 1e3
             text_mode_bytes = acc3["bytes"] // 2
         fm.close()
-    for ln in lanes:
+    for ln in open_lanes:
         ln["miner"].close()
 
     if rank == 0:
@@ -768,10 +797,16 @@ def main():
                        "format_host_ms_per_step": format_host_ms,
                        "exchange_bytes_sent_per_step_rank0": tot["xsent"] / max(1, args.steps),
                        "exchange_bytes_received_per_step_rank0": tot["xrecv"] / max(1, args.steps),
+                       # collectives rank 0 issued per pass: one all-gather per level, or (owner mode) a gather and a broadcast per level,
+                       # over all its lanes
+                       "collectives_per_step_rank0": ((2 if owner_mode else 1) * tot.get("levels", 0) / max(1, args.steps)) if (world > 1 or forced) else 0,
+                       "lanes": nlanes,
                        "index_hbm_bytes": ix.device_bytes(), "wire_bytes_per_step": tot.get("wire_bytes", 0) / max(1, args.steps),
                        # the exact entropy (metaserver.cpp:379,389) is the host's libm: its version goes next to every result
                        "glibc": os.confstr("CS_GNU_LIBC_VERSION") if hasattr(os, "confstr") else None},
         }
+        if both is not None:
+            out["exchange_modes"] = both
         print("bench: gpu leg done: %.3e substrings/s, %.1f ms/step" % (out["value"], out["ms_per_step"]), file=sys.stderr, flush=True)
         default_cfg = world == 1 and args.nlocal == 1 and not args.stream_mode and not forced
         if default_cfg and not args.no_cpu:
