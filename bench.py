@@ -456,6 +456,9 @@ def main():
     def run_mode(mode):
         """one measurement (lanes, miners, warm-up, K timed steps) with the given exchange; the miners stay open (the caller closes them)"""
         owner_mode = mode == "owner" and (world > 1 or forced)
+        if owner_mode and world * args.nlocal < 2:
+            # (the owner partition lives in the several-sample engine: handles derived in the LF-step kernel)
+            raise SystemExit("bench: --exchange owner/both needs at least two samples in the job (--force-exchange at N=1: add --nlocal 2)")
         # owner mode wants at least as many prefixes as ranks (every rank the server of some prefix): two letters beyond four ranks
         plen = args.prefix_len if args.prefix_len >= 0 else (2 if owner_mode and world > 4 else 1)
         prefixes = ["".join(p) for p in itertools.product("ACGT", repeat=plen)] if plen > 0 else [""]

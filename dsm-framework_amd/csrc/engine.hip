@@ -1895,6 +1895,7 @@ class Engine {
     u32* h_totals = nullptr;  // pinned: [0..7] u32 totals, [8..8+MAX_LOCAL) record allocations, [300..] u64 totals
     u64* h_childmax = nullptr;  // pinned: one per rank
     std::vector<void*> owned;
+    size_t owned_bytes = 0;   // device bytes behind `owned` (page-rounded)
     Arena arena;
     Arena earena;          // multi-rank: emission-side allocations
     Arena* ea = nullptr;   // &earena, or &arena in single-process runs
@@ -1927,6 +1928,7 @@ class Engine {
         hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
         if (e != hipSuccess) return fail(DSM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
         owned.push_back(q);
+        owned_bytes += ((n ? n : 1) * sizeof(T) + 4095) & ~(size_t)4095;
         p = (T*)q;
         return 0;
     }
@@ -2113,12 +2115,8 @@ class Engine {
         if (int rc = dalloc(d_pub_cmax, (size_t)(world > 0 ? world : 1))) return rc;
         DSM_HIP(hipHostMalloc((void**)&h_totals, 320 * sizeof(u32)));
         DSM_HIP(hipHostMalloc((void**)&h_childmax, (size_t)(world > 0 ? world : 1) * sizeof(u64)));
-        size_t used = 0;
-        {
-            size_t f2 = 0, t2 = 0;
-            DSM_HIP(hipMemGetInfo(&f2, &t2));
-            used = free_b - f2;
-        }
+        // what this miner took so far (its own count: the card's free memory also moves with the other lanes and ranks of a card)
+        const size_t used = owned_bytes;
         u64 arena_b = budget > used ? budget - used : 0;
         const u64 floor_b = p.arena_bytes ? (1u << 20) : (64u << 20);  // an explicit budget is honoured down to 1 MiB
         if (arena_b < floor_b) arena_b = floor_b;
@@ -3184,6 +3182,7 @@ struct MinerT : MinerBase {
         int rc = e.run(prefix.c_str(), ts, nullptr, ctx, emit, lo, ~0u, ~0u, seed);
         if (rc != DSM_E_CAPACITY || prefix.size() >= 32) return rc;
         ++e.splits;
+        if (getenv("DSM_TRACE_SPLITS")) fprintf(stderr, "dsm split rank=%d prefix=%s Fcap=%u: %s\n", e.rank, prefix.c_str(), e.Fcap, dsm_last_error());
         const u32 k = (u32)prefix.size();
         NodeOrder cap;  // shallow pass: the children of the prefix node with all four siblings visible -> their orders
         cap.depth = k + 1;
@@ -3217,6 +3216,7 @@ struct MinerT : MinerBase {
             return rc;
         }
         ++e.splits;
+        if (getenv("DSM_TRACE_SPLITS")) fprintf(stderr, "dsm split rank=%d prefix=%s Fcap=%u: %s\n", e.rank, prefix.c_str(), e.Fcap, dsm_last_error());
         NodeOrder cap;  // shallow pass: which bases continue p
         cap.depth = k + 1;
         rc = e.run(prefix.c_str(), nullptr, nullptr, ctx, false, 1, ~0u, k + 1, nullptr, &cap);

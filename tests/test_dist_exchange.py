@@ -421,6 +421,8 @@ def test_bench_two_ranks_sharing_the_card_over_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["exchange"].startswith("torch.distributed") and "2 prefix lane(s)" in d["config"]["parallelism"]
     assert d["detail"]["union_nodes_per_step"] > d["detail"]["rank0_nodes_per_step"] > 0   # two samples: the union trie is larger than one sample's
+    # (the arena is sized from the miner's own allocations, not from the card's free memory, which moves with the other rank of the card)
+    assert d["detail"]["prefix_splits_per_step"] == 0
     # the same launch line in owner mode: prefix k merged by rank k % 2 alone, one lane per owner; same nodes, same tuples
     o = launch(["--exchange", "owner"])
     assert "merged by rank k % 2" in o["config"]["parallelism"] and o["n_gpus"] == 2
