@@ -340,27 +340,13 @@ struct DevBuf {
     T* release() { T* q = p; p = nullptr; return q; }
 };
 
-static int open_impl(const char* path, int device, unsigned flags, dsm_index** out) {
-    if (!path || !out) return fail(DSM_E_INVAL, "dsm_index_open: null argument");
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(DSM_E_NODEV, "dsm_index_open: no HIP device (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_index_open: bad device ordinal");
-    DSM_HIP(hipSetDevice(device));
-
-    // The file is mapped, not read: the header is parsed in place and the bit vectors go from the page cache through pinned
-    // staging buffers to the card on several threads (a vector + fread + pageable hipMemcpy moved every byte three times on one).
-    MappedFile file;
-    if (int rc = file.open(path)) return rc;
-    const size_t fsz = file.n;
-
-    Parser r{file.p, fsz};
+// The file's header, code table and wavelet-tree shape, parsed in place and checked the way FMIndex::load / metaenumerate do
+// (FMIndex.cpp:305-372, metaenumerate.cpp:243-247).  Host work only: dsm_index_probe runs it without a device.
+static int parse_header(const MappedFile& file, IndexMeta& m, std::vector<HostNode>& nodes) {
+    Parser r{file.p, file.n};
     u8 ver = r.rd<u8>();
     if (!r.ok || (ver != 17 && ver != 16 && ver != 15 && ver != 14))
         return fail(DSM_E_FORMAT, "FMIndex: invalid save file version (expected 14..17)");
-    std::unique_ptr<dsm_index> ix(new dsm_index());
-    IndexMeta& m = ix->meta;
     m.n = r.rd<u64>();
     (void)r.rd<u32>();  // samplerate
     for (int i = 0; i < 256; ++i) m.C[i] = ver == 14 ? (u64)r.rd<u32>() : r.rd<u64>();
@@ -370,7 +356,6 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
         m.codes[i].bits = r.rd<u32>();
         m.codes[i].code = r.rd<u32>();
     }
-    std::vector<HostNode> nodes;
     if (r.ok) parse_node(r, nodes, 0);
     (void)r.rd<u32>();  // numberOfTexts
     (void)r.rd<u64>();  // maxTextLength
@@ -419,6 +404,26 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
         ++m.ncodes;
     }
     for (int k = m.ncodes; k < 8; ++k) m.code2byte[k] = 0;
+    return 0;
+}
+
+static int open_impl(const char* path, int device, unsigned flags, dsm_index** out) {
+    if (!path || !out) return fail(DSM_E_INVAL, "dsm_index_open: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DSM_E_NODEV, "dsm_index_open: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(DSM_E_NODEV, "dsm_index_open: bad device ordinal");
+    DSM_HIP(hipSetDevice(device));
+
+    // The file is mapped, not read: the header is parsed in place and the bit vectors go from the page cache through pinned
+    // staging buffers to the card on several threads (a vector + fread + pageable hipMemcpy moved every byte three times on one).
+    MappedFile file;
+    if (int rc = file.open(path)) return rc;
+    std::unique_ptr<dsm_index> ix(new dsm_index());
+    IndexMeta& m = ix->meta;
+    std::vector<HostNode> nodes;
+    if (int rc = parse_header(file, m, nodes)) return rc;
 
     // ---- upload the raw wavelet tree ----------------------------------------------------------
     std::vector<WtNodeDev> wn(nodes.size());
@@ -501,7 +506,7 @@ static int open_impl(const char* path, int device, unsigned flags, dsm_index** o
         std::vector<u64> sbh(nsb * 4);
         DSM_HIP(hipMemcpy(sbh.data(), d_sbase.p, sbh.size() * 8, hipMemcpyDeviceToHost));
         for (u64 s = 0; s < nsb; ++s)
-            for (int c = 0; c < 4; ++c) sbh[s * 4 + c] += m.C[(int)bases[c]];
+            for (int c = 0; c < 4; ++c) sbh[s * 4 + c] += m.C[(int)"ACGT"[c]];
         DSM_HIP(hipMemcpy(d_sbase.p, sbh.data(), sbh.size() * 8, hipMemcpyHostToDevice));
     }
     ix->device = device;
@@ -576,6 +581,18 @@ const char* dsm_last_error(void) { return dsm::g_err.c_str(); }
 int dsm_abi_version(void) { return DSM_ABI_VERSION; }
 
 int dsm_index_open(const char* p, int device, dsm_index** out) { return open_impl(p, device, 0, out); }
+int dsm_index_probe(const char* path, uint64_t* n_out) {
+    if (!path) return fail(DSM_E_INVAL, "dsm_index_probe: null argument");
+    MappedFile file;
+    if (int rc = file.open(path)) return rc;
+    IndexMeta m;
+    std::vector<HostNode> nodes;
+    if (int rc = parse_header(file, m, nodes)) return rc;
+    for (const HostNode& h : nodes)  // every bit vector the header promises lies inside the file
+        if (!h.leaf && (h.data_pos > file.n || 8 * h.integers > file.n - h.data_pos)) return fail(DSM_E_IO, "truncated or corrupt .fmi");
+    if (n_out) *n_out = m.n;
+    return 0;
+}
 int dsm_index_open_ex(const char* p, int device, unsigned flags, dsm_index** out) { return open_impl(p, device, flags, out); }
 
 void dsm_index_close(dsm_index* ix) {

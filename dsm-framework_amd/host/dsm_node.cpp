@@ -74,6 +74,20 @@ struct Rendezvous {
     }
 };
 
+// Before any communicator, stream or thread exists: every device ordinal is one of this node's cards and every sample is an index
+// this library can open (dsm_index_probe: header, code table and tree shape, host work only).  What can still fail later (device
+// memory) fails inside the rank threads, whose rendezvous keeps the others out of the collectives.
+static int validate_inputs(const std::vector<int>& devs, const std::vector<std::string>& files) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { std::cerr << "dsm_node: no HIP device" << std::endl; return 1; }
+    for (int d : devs)
+        if (d < 0 || d >= ndev) { std::cerr << "dsm_node: --devices: no device " << d << " (this node has " << ndev << ")" << std::endl; return 1; }
+    int bad = 0;
+    for (const std::string& f : files)
+        if (dsm_index_probe(f.c_str(), nullptr)) { std::cerr << "dsm_node: " << f << ": " << dsm_last_error() << std::endl; bad = 1; }
+    return bad;
+}
+
 struct Rank {
     Fmt fmt;
     int rank = 0, world = 1, device = 0;
@@ -167,11 +181,7 @@ static int run_devices(const std::vector<int>& devs, const dsm_params& p, const 
                 std::cerr << "dsm_node: --devices needs prefixes none of which starts with another (" << prefixes[a] << ", " << prefixes[b] << ")" << std::endl;
                 return 1;
             }
-    for (const std::string& f : files) {  // unreadable files are reported before any device or communicator is touched
-        FILE* t = fopen(f.c_str(), "rb");
-        if (!t) { std::cerr << "dsm_node: cannot read " << f << std::endl; return 1; }
-        fclose(t);
-    }
+    if (int rc = validate_inputs(devs, files)) return rc;
     std::vector<ncclComm_t> comms(G);
     if (ncclCommInitAll(comms.data(), G, devs.data()) != ncclSuccess) { std::cerr << "dsm_node: ncclCommInitAll failed" << std::endl; return 1; }
     std::vector<std::string> out(prefixes.size());
@@ -250,6 +260,7 @@ static int run_devices_owner(const std::vector<int>& devs, const dsm_params& p0,
                 std::cerr << "dsm_node: --devices needs prefixes none of which starts with another (" << prefixes[a] << ", " << prefixes[b] << ")" << std::endl;
                 return 1;
             }
+    if (int rc = validate_inputs(devs, files)) return rc;
     std::vector<std::vector<uint8_t>> ids(G, std::vector<uint8_t>(DSM_RCCL_ID_BYTES));
     for (int j = 0; j < G; ++j)
         if (dsm_rccl_unique_id(ids[j].data())) { std::cerr << "dsm_node: " << dsm_last_error() << std::endl; return 1; }

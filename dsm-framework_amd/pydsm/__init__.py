@@ -91,6 +91,7 @@ def lib():
         L.dsm_rccl_bcast.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dsm_index_open_ex.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
         L.dsm_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.dsm_index_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
         L.dsm_index_close.argtypes = [C.c_void_p]
         L.dsm_index_length.restype = C.c_uint64
         L.dsm_index_length.argtypes = [C.c_void_p]
@@ -170,6 +171,13 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise DsmError(rc, lib().dsm_last_error().decode(errors="replace"))
+
+
+def probe(path):
+    """dsm_index_probe: the checks of opening an index (header, code table, tree shape) on the host alone; returns the BWT length"""
+    n = C.c_uint64(0)
+    _check(lib().dsm_index_probe(os.fsencode(path), C.byref(n)))
+    return int(n.value)
 
 
 class Index:

@@ -59,6 +59,11 @@ typedef struct dsm_code {
 
 int dsm_index_open(const char* fmi_path, int device, dsm_index** out);
 int dsm_index_open_ex(const char* fmi_path, int device, unsigned flags, dsm_index** out);
+/* The checks of dsm_index_open without a device: header, code table and wavelet-tree shape of the file (FMIndex.cpp:305-372,
+ * metaenumerate.cpp:243-247: version, counts that add up to n, not color coded, every bit vector inside the file).  Host work only --
+ * a driver validates every sample with it before it creates communicators or threads that a late failure would leave hanging.
+ * *n (may be NULL) = BWT length. */
+int dsm_index_probe(const char* fmi_path, uint64_t* n);
 void dsm_index_close(dsm_index* idx);
 /* TextCollection::getLength(), FMIndex.h:68-69 */
 uint64_t dsm_index_length(const dsm_index* idx);

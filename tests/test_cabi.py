@@ -55,3 +55,34 @@ def test_open_errors_are_reported_not_fatal(tmp_path):
     import pydsm
     with pytest.raises(pydsm.DsmError):
         pydsm.Index(str(tmp_path / "missing.fmi"))
+
+
+def test_index_probe_validates_files_on_the_host(golden, tmp_path):
+    """dsm_index_probe: the header checks of FMIndex::load / metaenumerate (FMIndex.cpp:305-372, metaenumerate.cpp:243-247) without a
+    device -- what dsm_node --devices runs over every sample before it creates a communicator or a thread."""
+    import pydsm
+    good = golden.fmi("toy3", "toy-1")
+    n = pydsm.probe(good)
+    assert n > 0
+    raw = open(good, "rb").read()
+    for name, data, code in (("cut-header.fmi", raw[:1000], -5), ("cut-body.fmi", raw[:len(raw) - len(raw) // 3], -5),
+                             ("version.fmi", b"\x0d" + raw[1:], -74), ("empty.fmi", b"", -5)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(pydsm.DsmError) as e:
+            pydsm.probe(str(p))
+        assert e.value.code == code, (name, e.value.code, str(e.value))
+    # counts that do not add up to n (a wrapped 32-bit count): refused, as when opening
+    bad = bytearray(raw)
+    off = 1 + 8 + 4 + 256 * (4 if raw[0] == 14 else 8) + 8   # the code table: {count, bits, code} x 256
+    csz = 4 if raw[0] < 16 else 8
+    a = off + ord("A") * (csz + 8)
+    bad[a] ^= 1
+    p = tmp_path / "counts.fmi"
+    p.write_bytes(bytes(bad))
+    with pytest.raises(pydsm.DsmError) as e:
+        pydsm.probe(str(p))
+    assert "sum to n" in str(e.value)
+    with pytest.raises(pydsm.DsmError) as e:
+        pydsm.probe(str(tmp_path / "missing.fmi"))
+    assert e.value.code == -2

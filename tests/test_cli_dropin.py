@@ -64,6 +64,30 @@ def test_dsm_node_device_list_runs_the_exchange_on_rccl(golden, tmp_path):
     assert r.returncode == 1 and b"multiple of the number of devices" in r.stderr
 
 
+def test_dsm_node_device_list_validates_every_input_first(golden, tmp_path):
+    """--devices, both exchanges: every sample is validated (dsm_index_probe) and every device ordinal checked BEFORE a communicator,
+    stream or rank thread exists -- a bad sample among good ones is named and the process leaves with 1 instead of leaving ranks in a
+    collective (the reference's client stops in main() before it connects, metaenumerate.cpp:226-247)."""
+    names = golden.manifest["sets"]["toy3"]["names"]
+    fmis = [golden.fmi("toy3", n) for n in names]
+    raw = open(fmis[1], "rb").read()
+    cut = tmp_path / "cut.fmi"
+    cut.write_bytes(raw[:len(raw) // 2])
+    ver = tmp_path / "version.fmi"
+    ver.write_bytes(b"\x0d" + raw[1:])
+    for ex in ("allgather", "owner"):
+        base = [os.path.join(HOST, "dsm_node"), "--devices", "0", "--exchange", ex, "-E", "2.0", "-f", "2", "-p", "A,C"]
+        r = subprocess.run(base + [fmis[0], str(cut), str(ver)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and r.stdout == b""
+        assert b"cut.fmi: truncated or corrupt .fmi" in r.stderr and b"version.fmi: FMIndex: invalid save file version" in r.stderr
+        assert b"device 0:" not in r.stderr     # (reported by main(), not by a rank thread)
+        r = subprocess.run(base + [fmis[0], str(tmp_path / "missing.fmi"), fmis[2]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and b"missing.fmi: file not found" in r.stderr
+        r = subprocess.run([os.path.join(HOST, "dsm_node"), "--devices", "0,97,98", "--exchange", ex, "-E", "2.0", "-p", "A"] + fmis,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and b"no device 97" in r.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "metaenumerate_patched")), reason="oracle/_ref/metaenumerate_patched not present")
 def test_patched_reference_client_sends_the_reference_streams(golden):
     """INTEGRATION.md section 2, compiled: the reference metaenumerate with its EnumerateQuery::enumerate call replaced by
