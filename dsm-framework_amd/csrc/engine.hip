@@ -1863,6 +1863,12 @@ class Engine {
     u32 pub_seq = 0;          // sequence number of the last publish kernel
     u32 Seg = 0;              // handles per symbol segment of a record buffer: Fcap rounded up to whole tiles
     u32 Rcap = 0;             // handles of a record buffer = 4 * Seg
+    // A level whose records are WIDE (the few at the top of a prefix) numbers its handles with a smaller segment: a wide record is 81
+    // bytes with 64-bit positions, the compact one 32 and complete in itself, and the buffers are sized for Fcap compact records -- a
+    // level as wide as the capacity is always compact.  A wide level of more than FcapW nodes splits the prefix like any level that
+    // does not fit.  (32-bit positions: the 16-byte compact record keeps slots 2, 3 in the wide fields; one segment size.)
+    u32 FcapW = 0, SegW = 0, RcapW = 0;
+    u32 seg_of(bool compact) const { return compact ? Seg : SegW; }
     u32* d_pub_tot = nullptr; u64* d_pub_cmax = nullptr;  // device side of what publish_kernel hands over
     std::vector<P*> rec[2];     // child records, ping-pong by level
     std::vector<u32*> rp[2];    // record handle per frontier node, ping-pong
@@ -2003,7 +2009,9 @@ class Engine {
         }
         if (budget > free_b) budget = (u64)(free_b * 0.9);
         // bytes per unit of frontier capacity
-        u64 perF = (u64)nlocal * (2 * (REC_FIELDS * sizeof(P) + 1) * 4 + 2 * 4 + 4 + 1)   // rec x2 (four symbol segments each), rp x2, tpos, planes
+        const bool small_rec = sizeof(P) == 8 && !trie_mode;   // record buffers sized by the compact record (see FcapW)
+        const u64 rec_b = small_rec ? 32 : REC_FIELDS * sizeof(P) + 1;
+        u64 perF = (u64)nlocal * (2 * rec_b * 4 + 2 * 4 + 4 + 1)   // rec x2 (four symbol segments each), rp x2, tpos, planes
                    + (u64)nlocal * (sizeof(P) + 1)                             // send
                    + 2ull * d * (sizeof(P) + 1)                                // recv x2
                    + 2 * (2 + 1 + 8) + 1 + 16 + 64 + (d > 13 ? 4ull * d : 0) + (d > 1 ? 8 : 0);
@@ -2041,6 +2049,15 @@ class Engine {
         // Record handles: four symbol segments of Seg handles, a tile of 256 parents owns 256 handles in each (see the record layout)
         Seg = (Fcap + TILE - 1) / TILE * TILE;
         Rcap = 4 * Seg;
+        SegW = Seg; FcapW = Fcap;
+        if (small_rec) {
+            SegW = (u32)((u64)Seg * 32 / (REC_FIELDS * sizeof(P) + 1)) / TILE * TILE;
+            if (SegW < TILE) SegW = TILE;
+            FcapW = SegW < Fcap ? SegW : Fcap;
+        }
+        RcapW = 4 * SegW;
+        // (elements of P: the wide layout over RcapW handles, or 32-byte compact records over Rcap)
+        const size_t rec_n = std::max(rec_elems<P>(RcapW), small_rec ? (size_t)Rcap * 32 / sizeof(P) : (size_t)0);
         const size_t ntile = Seg / TILE, nwave = ntile * 4;
         const u64 slots = (u64)Fcap * 4;
         for (int s = 0; s < nlocal; ++s) {
@@ -2048,8 +2065,8 @@ class Engine {
             u32 *r0, *r1, *tp = nullptr;
             u64* pln = nullptr;
             if (!trie_mode) {
-                if (int rc = dalloc(a, rec_elems<P>(Rcap))) return rc;
-                if (int rc = dalloc(b, rec_elems<P>(Rcap))) return rc;
+                if (int rc = dalloc(a, rec_n)) return rc;
+                if (int rc = dalloc(b, rec_n)) return rc;
                 if (int rc = dalloc(pln, nwave * (d == 1 ? 8 : 4))) return rc;  // (one sample: whole lines per tile, see ExpandArgs::symbol_phase)
             } else {
                 if (int rc = dalloc(tp, (size_t)Fcap)) return rc;
@@ -2255,8 +2272,8 @@ class Engine {
                 if (cnt) { h[2 + 2 * slot] = (P)lo; h[3 + 2 * slot] = (P)(lo + cnt - 1); ++slot; hmask |= (u8)(1u << a); }
             }
             for (int f = 0; f < REC_FIELDS; ++f)
-                DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * Rcap, &h[f], sizeof(P), hipMemcpyHostToDevice, st));
-            DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)REC_FIELDS * Rcap, &hmask, 1, hipMemcpyHostToDevice, st));
+                DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)f * RcapW, &h[f], sizeof(P), hipMemcpyHostToDevice, st));   // (the root's record is wide)
+            DSM_HIP(hipMemcpyAsync(rec[0][s] + (size_t)REC_FIELDS * RcapW, &hmask, 1, hipMemcpyHostToDevice, st));
             const u32 zero = 0;
             DSM_HIP(hipMemcpyAsync(rp[0][s], &zero, sizeof(u32), hipMemcpyHostToDevice, st));
             if (self_mode) {  // the root as "child A of parent 0" of a level above it: slot 0, plane bit 0, handle 0
@@ -2322,14 +2339,17 @@ class Engine {
             u8* send = multi ? xsend : xrecv[xcur];
             ExpandArgs ea;
             memset(&ea, 0, sizeof ea);
-            ea.F = F; ea.cap = Rcap; ea.seg = Seg; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w9 ? 2u : (w16 ? 1u : 0u);
+            ea.F = F; ea.nbp = (F + TILE - 1) / TILE; ea.fmin = prm.fmin; ea.w16 = w9 ? 2u : (w16 ? 1u : 0u);
+            // handle spaces: the children's records are compact iff this level is narrow (w16), this level's iff its parent level was (fmt_in)
+            ea.seg = seg_of(w16 && !trie_mode); ea.cap = 4 * ea.seg;
+            ea.seg_in = seg_of(fmt_in); ea.cap_in = 4 * ea.seg_in;
             const bool nm = w9 && nlocal > 1 && !trie_mode;  // node-major packed columns (Xchg::nm)
             ea.cstride = nm ? (u32)nlocal : 1u;
             if (dynamic) {
                 ea.dyn = d_dyn;
                 ea.dyn_mask = pack_columns ? 3u : 1u;
                 ea.dyn_expect = ((w16 ? 0u : 1u) | (w9 ? 0u : 2u)) & ea.dyn_mask;
-                ea.fcap = Fcap;
+                ea.fcap = w16 ? Fcap : FcapW;
             }
             unsigned long long* d_childmax = reinterpret_cast<unsigned long long*>(send);  // header, cleared by the previous level's publish kernel
             if (depth < prefix.size()) {
@@ -2472,7 +2492,7 @@ class Engine {
                     if (F > stats.max_frontier) stats.max_frontier = F;
                     ++stats.levels;
                     if (trace_levels) fprintf(stderr, "dsm level prefix=%s depth=%u F=%u (client of rank %d)\n", prefix.c_str(), depth, F, owner);
-                    if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
+                    if (Fn > (w16 ? Fcap : FcapW)) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
                     if (!Fn) break;
                     const u64* planes = reinterpret_cast<const u64*>(bc_buf + 16);
                     const u32 nbp = (F + TILE - 1) / TILE;
@@ -2557,7 +2577,7 @@ class Engine {
             }
             ao.parent_nT = nT[cur]; ao.nlocal = (u32)nlocal; ao.rank = (u32)rank;
             ao.cap = (u32)((size_t)F * 4 < Fcap ? (size_t)F * 4 : Fcap);
-            ao.seg = Seg;
+            ao.seg = seg_of(w16 && !trie_mode);  // (of the records this level's LF-step launch wrote: the children's)
             ao.h_totals = d_pub_tot;
             ao.rp = d_rp_tab[nxt];
             ao.rp0 = rp[nxt][0];
@@ -2638,10 +2658,11 @@ class Engine {
             w16 = !(pk[1] >> 31) && !trie_mode;  // the next level's frequencies all fit 16 bits (parsed streams stay wide)
             w9 = w16 && !((pk[1] >> 30) & 1u) && pack_columns;  // ... and nine: frequency and flags share a 16-bit word
             // did the launch queued ahead run?  (the kernel tested the same two words the packet carries)
-            const bool spec_hit = spec && Fn > 0 && Fn <= Fcap && w16 == spec_w16 && (!pack_columns || ((pk[1] >> 30) & 1u) == (spec_w9 ? 0u : 1u));
+            const bool spec_hit = spec && Fn > 0 && Fn <= (w16 ? Fcap : FcapW) && w16 == spec_w16 && (!pack_columns || ((pk[1] >> 30) & 1u) == (spec_w9 ? 0u : 1u));
             if (spec && !spec_hit) --stats.expand_launches;  // (the launch queued ahead found no level, or another class, and did nothing)
             h_totals[300] = pk[2]; h_totals[301] = pk[3];  // candidate totals of this level (read by emit_store)
-            if (Fn > Fcap) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");  // (the clients read the same width and stop too)
+            // (a level of wide records has the smaller capacity FcapW; every rank, and in owner mode every client, sees the same two numbers)
+            if (Fn > (w16 ? Fcap : FcapW)) return fail(DSM_E_CAPACITY, "frontier wider than the device buffers: use a longer prefix or a larger arena_bytes");
             if (owner_mode) {  // what the clients do next: send the next level's columns and wait for its answer, or wait for the final verdict
                 if (!Fn) owed.arm(16);
                 else owed.arm_next((size_t)((((u64)nlocal * Fn * (w9 ? 2u : (w16 ? 3u : (u32)sizeof(P) + 1)) + 15) & ~15ull) + 16), xrecv[xcur ^ 1], 16 + (size_t)((Fn + 63) >> 6) * 32);

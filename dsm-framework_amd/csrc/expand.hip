@@ -205,11 +205,17 @@ __device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<
     n.ep = n.live ? sp + (v.z & 0xFFFFu) : 0ull;
     n.e0min = sp + (v.z >> 16); n.e0max = sp + (v.w & 0xFFFFu);
     n.e1min = sp + (v.w >> 16); n.e1max = sp + (x.x & 0xFFFFu);
+    n.e2min = sp + (x.y & 0xFFFFu); n.e2max = sp + (x.y >> 16);   // (the 32-byte record holds all four slots)
+    n.e3min = sp + (x.z & 0xFFFFu); n.e3max = sp + (x.z >> 16);
     n.emask = n.live ? (x.x >> 16) & 15u : 0u;
 }
-// A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions (slots 2, 3 went to the wide fields already)
+// A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions.  Slots 2, 3: written to the wide fields already,
+// except for the compact record of 64-bit positions, which takes them as packed 16-bit offsets (o2, o3: min | max << 16).
+template <typename P>
+constexpr bool slots_inline(bool compact) { return compact && sizeof(P) == 8; }
 template <typename P, bool OUTC>
-__device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32 q, P nsp, P nep, P l0, P h0, P l1, P h1, u32 cn, u32 cm) {
+__device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32 q, P nsp, P nep, P l0, P h0, P l1, P h1, u32 cn, u32 cm,
+                                            u32 o2 = 0, u32 o3 = 0) {
     if (OUTC) {
         uint4* c = reinterpret_cast<uint4*>(out) + (size_t)q * CREC_WORDS(sizeof(P));
         const u32 len = (u32)(nep - nsp), a0 = cn > 0 ? (u32)(l0 - nsp) : 0u, b0 = cn > 0 ? (u32)(h0 - nsp) : 0u,
@@ -218,7 +224,7 @@ __device__ __forceinline__ void store_child(P* __restrict__ out, size_t cap, u32
             c[0] = make_uint4((u32)nsp, len | (a0 << 16), b0 | (a1 << 16), b1 | (cm << 16));
         } else {
             c[0] = make_uint4((u32)nsp, (u32)((u64)nsp >> 32), len | (a0 << 16), b0 | (a1 << 16));
-            c[sizeof(P) == 4 ? 0 : 1] = make_uint4(b1 | (cm << 16), 0u, 0u, 0u);
+            c[sizeof(P) == 4 ? 0 : 1] = make_uint4(b1 | (cm << 16), cn > 2 ? o2 : 0u, cn > 3 ? o3 : 0u, 0u);
         }
     } else {
         out[q] = nsp;
@@ -300,7 +306,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                                             const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab, const u32 cost_pack) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
-    const size_t cap = a.cap;
+    const size_t cap = a.cap, capi = a.cap_in;   // handle spaces of the children's records and of this level's
     const u32 i = t * 64 + lane;
     const u32 drawn = seq.issue();  // (the wave's tile after next, or three ahead: taken where its handles are requested)
     NodeIn<P> nd;
@@ -372,13 +378,13 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             const u32 ifar = tfar * 64 + lane;
             const bool infar = tfar < ntile && ifar < a.F;
             if (SELF) {
-                load_head<P>(rec, cap, self_handle(ss->s1, ss->pn, a.seg), hn);
+                load_head<P>(rec, capi, self_handle(ss->s1, ss->pn, a.seg_in), hn);
                 ss->pn = pplane[self_plane_index(ss->s2)];
                 ss->s1 = ss->s2;
                 const u32 v = rp[infar ? ifar : 0u];
                 ss->s2 = infar ? v : DEAD;
             } else {
-                load_head<P>(rec, cap, rn, hn);
+                load_head<P>(rec, capi, rn, hn);
 #ifdef DSM_LF_SENS_STREAM  // sensitivity probe: 16 more bytes per node streamed in (the lines the children's records will be written to)
                 sens0 = reinterpret_cast<const uint4*>(out)[(size_t)(rn != DEAD ? rn : 0u)];
 #endif
@@ -492,13 +498,13 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     }
     // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
     bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
-    if (!INC) {
+    if (!INC || slots_inline<P>(INC)) {
         matches = matches || (ne > 2 && nd.e2min == sp && nd.e2max == ep) || (ne > 3 && nd.e3min == sp && nd.e3max == ep);
     } else if (__any(ne > 2)) {  // third / fourth interval of a node (well under one node in a hundred): read here and again by its pairs
         if (ne > 2) {
 #pragma unroll
             for (int e = 2; e < 4; ++e)
-                if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * cap + nd.r] == sp && rec[(size_t)(3 + 2 * e) * cap + nd.r] == ep) matches = true;
+                if ((u32)e < ne && rec[(size_t)(2 + 2 * e) * capi + nd.r] == sp && rec[(size_t)(3 + 2 * e) * capi + nd.r] == ep) matches = true;
         }
     }
     const u32 mycode = !live ? 0u : (matches ? 1u + (31u - (u32)__clz((int)emask)) : (ne ? 5u : 0u));
@@ -525,6 +531,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         // together), and every child takes its base's pair of ranks: at most eight loads per node, four rounds.
         u32 cn4 = 0, cm4 = 0;   // per child: intervals kept so far (3 bits each), their mask (4 bits each)
         P kl0[4] = {0, 0, 0, 0}, kh0[4] = {0, 0, 0, 0}, kl1[4] = {0, 0, 0, 0}, kh1[4] = {0, 0, 0, 0};  // (compact children only: their first two)
+        u32 ko2[4] = {0, 0, 0, 0}, ko3[4] = {0, 0, 0, 0};   // (... of 64-bit positions: the other two as offsets, see store_child)
         const u32 kkpack = bit_list(emask);
         P prevx = 0, prevR[4] = {0, 0, 0, 0};
 #pragma nounroll
@@ -567,6 +574,10 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                     const u32 cnc = (cn4 >> (3 * c)) & 7u;
                     if (OUTC && cnc == 0) { kl0[c] = l; kh0[c] = h - 1; }
                     else if (OUTC && cnc == 1) { kl1[c] = l; kh1[c] = h - 1; }
+                    else if (slots_inline<P>(OUTC)) {
+                        const u32 o = (u32)(l - Rsp[c]) | ((u32)(h - 1 - Rsp[c]) << 16);
+                        if (cnc == 2) ko2[c] = o; else ko3[c] = o;
+                    }
                     else { out[(size_t)(2 + 2 * cnc) * cap + qa[c]] = l; out[(size_t)(3 + 2 * cnc) * cap + qa[c]] = h - 1; }
                     cn4 += 1u << (3 * c);
                     cm4 |= 1u << (4 * c + kk);
@@ -579,14 +590,14 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         for (int c = 0; c < 4; ++c) {
             if ((present >> c) & 1u) {
                 const u32 cnc = (cn4 >> (3 * c)) & 7u, cmc = (cm4 >> (4 * c)) & 15u;
-                if (OUTC) store_child<P, true>(out, cap, qa[c], Rsp[c], Rep[c] - 1, kl0[c], kh0[c], kl1[c], kh1[c], cnc, cmc);
+                if (OUTC) store_child<P, true>(out, cap, qa[c], Rsp[c], Rep[c] - 1, kl0[c], kh0[c], kl1[c], kh1[c], cnc, cmc, ko2[c], ko3[c]);
                 else {
                     out[qa[c]] = Rsp[c];
                     out[cap + qa[c]] = Rep[c] - 1;
                     reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[qa[c]] = (u8)cmc;
                 }
                 if (!OUTC) acc.rb_lane += (cnc < 2 ? cnc : 2u) * 2u * (u32)sizeof(P);
-                if (cnc > 2) acc.rb_lane += (cnc - 2) * 2u * (u32)sizeof(P);
+                if (cnc > 2 && !slots_inline<P>(OUTC)) acc.rb_lane += (cnc - 2) * 2u * (u32)sizeof(P);
             }
         }
     } else
@@ -596,6 +607,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         const u32 cjpack = bit_list(present), kkpack = bit_list(emask);  // two bits per slot: bases of the children / of the intervals, in order
         u32 cn = 0, cm = 0;               // number and mask of the intervals the current child has kept
         P kl0 = 0, kh0 = 0, kl1 = 0, kh1 = 0;  // the first two of them
+        u32 ko2 = 0, ko3 = 0;                  // (64-bit positions, compact children: the other two as offsets, see store_child)
         P prevx = 0, prevh = 0;                // upper end of the previous pair's interval and its rank (same child when e > 0)
         u32 j = 0, e = 0;  // the pair at hand: child j (in base order), interval e of the parent
 #pragma nounroll
@@ -607,10 +619,12 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             if (e == 0) { cn = 0; cm = 0; }
             const bool hasext = act && ne > 0;
             P xmin = e == 0 ? nd.e0min : nd.e1min, xmax = e == 0 ? nd.e0max : nd.e1max;
-            if (__any(hasext && e > 1)) {
+            if constexpr (slots_inline<P>(INC)) {
+                if (e > 1) { xmin = e == 2 ? nd.e2min : nd.e3min; xmax = e == 2 ? nd.e2max : nd.e3max; }
+            } else if (__any(hasext && e > 1)) {
                 if (hasext && e > 1) {
-                    xmin = rec[(size_t)(2 + 2 * e) * cap + nd.r];
-                    xmax = rec[(size_t)(3 + 2 * e) * cap + nd.r];
+                    xmin = rec[(size_t)(2 + 2 * e) * capi + nd.r];
+                    xmax = rec[(size_t)(3 + 2 * e) * capi + nd.r];
                 }
             }
             const P xl = hasext ? xmin : sp, xh = hasext ? xmax + 1 : ep1;
@@ -638,15 +652,19 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             if (hasext && l <= h - 1) {
                 if (cn == 0) { kl0 = l; kh0 = h - 1; }
                 else if (cn == 1) { kl1 = l; kh1 = h - 1; }
+                else if (slots_inline<P>(OUTC)) {
+                    const u32 o = (u32)(l - nsp) | ((u32)(h - 1 - nsp) << 16);
+                    if (cn == 2) ko2 = o; else ko3 = o;
+                }
                 else { out[(size_t)(2 + 2 * cn) * cap + q] = l; out[(size_t)(3 + 2 * cn) * cap + q] = h - 1; }  // slots 2, 3: wide fields
                 ++cn;
                 cm |= 1u << kk;
             }
             if (act && e == ne1 - 1) {
-                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm);
+                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm, ko2, ko3);
                 // (bytes of the child's record beyond the compact word / the fixed fields: rare or wide levels only)
                 if (!OUTC) acc.rb_lane += (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P);
-                if (cn > 2) acc.rb_lane += (cn - 2) * 2u * (u32)sizeof(P);
+                if (cn > 2 && !slots_inline<P>(OUTC)) acc.rb_lane += (cn - 2) * 2u * (u32)sizeof(P);
             }
             ++e;
             if (e >= ne1) { e = 0; ++j; }
@@ -670,7 +688,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         // its own record (compact word, or sp, ep, mask and the two slots the head always reads; slots 2, 3 when in use) and its
         // children's (compact word each, or their fixed fields; what depends on the kept intervals is in rb_lane)
         acc.rbytes += nl * (INC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(6 * sizeof(P) + 1)) + nkids * (OUTC ? 16u * CREC_WORDS(sizeof(P)) : (u32)(2 * sizeof(P) + 1));
-        if (__any(ne > 2)) acc.rbytes += (mask_count(__ballot(ne > 2)) + mask_count(__ballot(ne > 3))) * 2u * (u32)sizeof(P);
+        if (!slots_inline<P>(INC) && __any(ne > 2)) acc.rbytes += (mask_count(__ballot(ne > 2)) + mask_count(__ballot(ne > 3))) * 2u * (u32)sizeof(P);
     }
 }
 
@@ -721,10 +739,10 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
             if (tC < ntile && i2 < a.F) ss.s2 = rp[i2];
             const u64 p0 = pplane[self_plane_index(r0)];
             ss.pn = pplane[self_plane_index(ss.s1)];
-            r0 = self_handle(r0, p0, a.seg);
+            r0 = self_handle(r0, p0, a.seg_in);
         }
         RecHead<P, INC> hA, hB;
-        load_head<P>(rec, a.cap, r0, hA);
+        load_head<P>(rec, a.cap_in, r0, hA);
         // two tiles per trip, the two head sets swapping roles: no register that a load is still filling is ever copied.
         // t0 / t1 / t2: the wave's current tile and the ones whose heads / slots are on their way (t2: SELF only).
         u32 t0 = tA, t1 = tB, t2 = tC, tf = ~0u;

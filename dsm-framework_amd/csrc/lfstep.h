@@ -31,7 +31,9 @@ constexpr u32 SB_LDS_MAX = 64;  // superblocks the LDS copy holds (2^37 symbols)
 //                            offsets from sp of the ends of slots 0 and 1, then the mask.  A level is compact when every frequency
 //                            of its parent level is below 65535.  One load / one store per record instead of seven: the LF-step
 //                            kernel is bound by the memory transactions it issues, not by their bytes.  The words share the
-//                            memory of fields 0-3 of the wide format (a level has one format).
+//                            memory of fields 0-3 of the wide format (a level has one format).  The 32-byte record of 64-bit
+//                            positions has room for the offsets of slots 2 and 3 as well and is complete in itself; the 16-byte one
+//                            keeps them in the wide fields 6-9.
 //
 // Order of a level.  The nodes of a level are kept in COLEX order of their paths (sorted by the reversed substring), not in
 // trie order.  The index holds reversed reads, so the suffix-array interval of a substring P is ordered by reverse(P):
@@ -61,8 +63,10 @@ constexpr u32 TILE = 256;             // parents per block of the advance kernel
 
 struct ExpandArgs {
     u32 F;            // frontier width
-    u32 cap;          // record capacity (stride of both record buffers) = 4 * seg
-    u32 seg;          // handles per symbol segment (>= F rounded up to a tile)
+    u32 cap;          // handle space of the record buffer the children are written to (stride of its wide fields) = 4 * seg
+    u32 seg;          // ... handles per symbol segment (>= F rounded up to a tile)
+    u32 cap_in;       // the same two numbers of the buffer this level's records were written to: a level picks its handle space by the
+    u32 seg_in;       // format of the records (a compact record is a fraction of a wide one, so compact levels may be wider: engine.hip)
     u32 nbp;          // tiles of the level = stride of cnt4
     u32 allowed;      // bit c set: child c may be tried (enforced prefix / maxdepth)
     u32 fmin;
