@@ -47,6 +47,8 @@ def parse():
                     "one RCCL all-gather per level through torch.distributed, lanes, status words) with a world of one")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra records of the default N=1 run (64-bit positions; eight samples on one GPU)")
+    ap.add_argument("--extras", default=os.environ.get("DSM_BENCH_EXTRAS", "all"),
+                    help="which extra records: all, or a comma list of u64,stream,server,d8,d64,big (big = configs[3]: 4-Gbase samples)")
     ap.add_argument("--pmin", type=int, default=-1, help="metaserver -P; default 1 for a single sample, else 2")
     ap.add_argument("--pmax", type=int, default=0, help="metaserver --pmax (BASELINE configs[3]: 8, configs[4]: 1)")
     ap.add_argument("--wide", action="store_true", help="force 64-bit positions (the code path of n > 2^32, BASELINE configs[3])")
@@ -226,12 +228,23 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
     def note(msg):
         print("bench: extra records: " + msg, file=sys.stderr, flush=True)
 
+    class Skip(Exception):
+        pass
+
+    def want(key):
+        if args.extras != "all" and key not in args.extras.split(","):
+            raise Skip()
+
     try:
+        want("u64")
         out.append(dict(one([ix], "same workload with 64-bit positions (wide=1)", pmin=pmin, wide=1), dtype="u64"))
+        note("64-bit positions done")
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "64-bit positions", "error": repr(e)})
-    note("64-bit positions done")
     try:  # the literal metaenumerate replacement: the wire stream of every prefix, through PCIe into a sink (EnumerateQuery.cpp:207-222)
+        want("stream")
         with pydsm.Miner([ix], fmin=args.fmin, stream=torch.cuda.current_stream().cuda_stream, stream_mode=True) as m:
             m.enumerate_many(prefixes, discard=True)
             torch.cuda.synchronize()
@@ -242,15 +255,21 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
         out.append({"record": "same workload as wire streams (stream mode: the client's bytes to a host sink)", "value": st.reported / dt,
                     "unit": "substrings/s", "ms_per_step": dt * 1e3, "nodes": st.reported, "wire_bytes": int(sum(nbs)),
                     "expand_ms": st.expand_ms, "device_ms": st.device_ms, "splits": st.splits, "dtype": "u32"})
+        note("wire-stream mode done")
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "wire-stream mode", "error": repr(e)})
-    note("wire-stream mode done")
     try:  # f2, the server side (metaserver.cpp:682-739): four clients' streams of prefix A, fed by four threads, merged WHILE they arrive
+        want("server")
         out.append(server_record(args, dev, local, pydsm))
+        note("server side done")
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "server side (merge while receiving)", "error": repr(e)})
-    note("server side done")
     try:
+        want("d8")
         a8 = argparse.Namespace(**vars(args))
         a8.gpus, a8.nlocal = 1, 8
         t0 = time.time()
@@ -264,11 +283,14 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
             out.append(rec)
         for x in ixs:
             x.close()
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "8 samples on one GPU", "error": repr(e)})
     try:  # BASELINE configs[4] at its real d: 64 read sets resident on the one card, -P 1 --pmax 1 (sample-specific substrings).  A tenth of
         # the default sample size, so that the 64 index builds keep the default run within minutes (the files
         # tests/test_many_samples_gpu.py builds: shared through DSM_BENCH_DIR)
+        want("d64")
         a64 = argparse.Namespace(**vars(args))
         a64.gpus, a64.nlocal = 1, 64
         a64.reads, a64.genome = max(1000, args.reads // 10), max(5000, args.genome // 10)
@@ -283,11 +305,14 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
             out.append(rec)
         for x in ixs:
             x.close()
+        note("64 samples done")
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "64 samples on one GPU (configs[4])", "error": repr(e)})
-    note("64 samples done")
     try:  # BASELINE configs[3]: 4-Gbase read sets (n = 8.08e9 > 2^32, real BWTs built here by dsm_bwt_build), first one alone, then
         # its one-card share: EIGHT of them resident (8 x 4 GB of index), d = 8, -P 2 --pmax 8
+        want("big")
         from pydsm import builder
         big = 4 * args.reads
         nbig = int(os.environ.get("DSM_BENCH_BIG_SAMPLES", "8"))
@@ -325,6 +350,8 @@ def extra_records(args, dev, local, pydsm, ix, path, prefixes, pmin):
                         "index_hbm_bytes": sum(x.device_bytes() for x in bixs)})
         for x in bixs:
             x.close()
+    except Skip:
+        pass
     except Exception as e:  # noqa: BLE001
         out.append({"record": "4-Gbase samples (configs[3])", "error": repr(e)})
     return out

@@ -619,6 +619,68 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
     }
 }
 
+// The down-sweep of ONE sample that is mined (no links, no reader counts, no stream records: path words and record handles only), the
+// case BASELINE's metric is quoted on.  advance_wave_kernel handles every mode with run-time flags and spends ~420 instructions per
+// wave of 64 parents -- more scalar than vector ones: the sweep is bound by their issue, not by the 21 bytes per node it moves.  Here a
+// WAVE takes a whole tile of 256 parents: the tile's four plane lines arrive through scalar loads, the counts before each of its four
+// rounds are scalar sums, no LDS and no barrier; the parents' path words of all four rounds are requested before the first is used.
+// (the line of a round, written by the LF-step kernel: {plane[4], candidate bits, candidates | pairs << 32, -, -}, ExpandArgs::symbol_phase)
+template <typename P>
+__global__ __launch_bounds__(256) void advance_single_kernel(u32 F, AdvanceOut o) {
+    const int lane = threadIdx.x & 63;
+    const u32 nw = (F + 63) >> 6;
+    const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
+    if (tile >= o.nbp) return;
+    const u64 lt = (1ull << lane) - 1;
+    const u64* __restrict__ line = o.kplane + (size_t)tile * 32;
+    // ---- requests: the parents' path words, the lines as the lanes will copy them, the tile's scanned counts ----
+    uint2 mypw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 u = (tile * 4 + (u32)q) * 64 + lane;
+        mypw[q] = o.parent_pw[u < F ? u : 0u];
+    }
+    u64 copyw = 0;
+    if (lane < 32) copyw = line[lane];
+    u32 cum[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cum[c] = o.cnt4[(size_t)c * o.nbp + tile];
+    u64 up[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) up[q][c] = tile * 4 + (u32)q < nw ? line[q * 8 + c] : 0ull;   // (planes exist for the waves that hold nodes only)
+    // ---- the retained directory of the level: planes and first-child indexes per round; the candidate words to their arrays ----
+    {
+        const u32 q = (u32)lane >> 3, j = (u32)lane & 7u, w = tile * 4 + q;
+        if (lane < 32 && w < nw) {
+            if (j < 4) o.kplane_w[(size_t)w * 4 + j] = copyw;
+            else if (o.cand_copy && j == 4) o.candbits[w] = copyw;
+            else if (o.cand_copy && j == 5) o.wsum[w] = copyw;
+        }
+    }
+    const u32 r = o.plevel & (PW_CHUNK - 1);
+    u32 kc = 0;   // lane 4q + c: index of the first child c of round q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 w = tile * 4 + (u32)q, u = w * 64 + lane;
+        const uint2 ppw = mypw[q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u64 m = up[q][c];
+            if (lane == q * 4 + c) kc = cum[c];
+            const u32 below = bits_below_lane(m);
+            const u32 vj = cum[c] + below;
+            if (((m >> lane) & 1ull) && vj < o.cap) {
+                o.rp0[vj] = (u32)c * o.seg + w * 64u + below;
+                o.pw[vj] = r == 0 ? make_uint2(u, (u32)c) : make_uint2(ppw.x, ppw.y | ((u32)c << (2 * r)));
+            }
+            cum[c] += (u32)__popcll(m);
+        }
+    }
+    if (lane < 16 && tile * 4 + ((u32)lane >> 2) < nw) o.kcum[(size_t)tile * 16 + lane] = kc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Owner mode, on the ranks that do NOT merge the prefix: the owner's broadcast carries the union's child planes of the level
 // (4 x 64 bits per 64 parents); from them a client only needs the next level's links (4 * parent + symbol), from which its
@@ -2610,7 +2672,10 @@ class Engine {
                 if (ao.single) ao.cand_copy = 1;  // (the level's LF-step kernel decided: the sweep only moves the words into place)
                 else ao.filter_on = 1;
             }
+            static const bool lean_sweep = !(getenv("DSM_LEAN_ADVANCE") && atoi(getenv("DSM_LEAN_ADVANCE")) == 0);
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
+            else if (lean_sweep && ao.single && ao.kshift == 3 && ao.pw && !ao.slot && !ao.sa && !ao.filter_on && ao.kplane_w)
+                hipLaunchKernelGGL((advance_single_kernel<P>), dim3((nbp + 3) / 4), dim3(256), 0, st, F, ao);
             else hipLaunchKernelGGL((advance_wave_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             if (filtered) {
                 if (int erc = emit_filter(me, F, depth, x, cur, order_mode, !fused_filter)) return erc;
