@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -97,6 +98,14 @@ __device__ __forceinline__ u32 xcd_block() {
 constexpr int NPT = 4;
 static inline dim3 grid_npt(u64 n) { return dim3((unsigned)((n + 256ull * NPT - 1) / (256ull * NPT))); }
 
+
+// DSM_TIMELINE=1: host time stamps of a mining call on stderr (milliseconds since the first stamp), a debugging aid
+static inline void timeline(const char* what, const char* arg = "") {
+    static const bool on = getenv("DSM_TIMELINE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "dsm timeline %9.3f ms  %s %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what, arg);
+}
 
 constexpr u32 BC_OK = 0x4f4b4f4bu, BC_CAPACITY = 0x46554c4cu, BC_ABORT = 0x41424f52u;  // first word of the owner's broadcast: go on / split this prefix / the owner failed
 constexpr u32 XHDR = 16;  // every rank's message starts with the largest child frequency it saw (u64) and 8 spare bytes
@@ -1124,9 +1133,27 @@ __global__ void chunk_bounds_kernel(ChunkBounds cbs, const u32* __restrict__ pat
 
 // Paths and pairs of all tuples.  Threads take the candidates level by level in node order.  A path is put together from the path
 // words of the node and of its ancestors at the chunk boundaries (levels 16, 32, ...): 16 symbols per dependent load.
+// What the host emitter used to compute per tuple (emit_job's first pass, 3.4 ms of sixteen threads per chunk of four million tuples,
+// in the open at the end of a pass): the exact entropy (metaserver.cpp:366-389 from the uploaded tables: the same entries added in the
+// same order, one division, one subtraction -- IEEE double, bit-identical to the host's), the emin / emax verdict (:413) and the offsets
+// relative to the chunk (a batch's offsets start at 0).  The thread that fills a tuple has its frequencies in registers.  A frequency or
+// a total beyond the tables (a few hundred nodes at the top of a pass) leaves the tuple to the host (EV_HOST).
+constexpr u8 EV_DROP = 0, EV_KEEP = 1, EV_HOST = 2;
+struct FillVerdict {
+    double* ent;          // per tuple (output rank); null: no verdicts (text mode computes its own)
+    u8* keep;
+    u32* rel_path;        // offsets relative to the chunk, chunk c at [rank_lo + c, rank_hi + c]
+    u32* rel_pair;
+    u32* counts;          // of the chunk: [0] dropped, [1] left to the host
+    const double* terms;  // device copies of term_table() / logn_table()
+    const double* logn;
+    u32 chunk, d;
+    u32 pb0, qb0;         // path byte / pair at which the chunk starts
+    double emin, emax;
+};
 __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const LevelDev* __restrict__ lv, const u32* __restrict__ path_off,
                                                          const u32* __restrict__ pair_off, char* __restrict__ paths, u32* __restrict__ ids,
-                                                         u64* __restrict__ freqs, u32 rank_lo, u32 rank_hi) {
+                                                         u64* __restrict__ freqs, u32 rank_lo, u32 rank_hi, FillVerdict fv) {
     // the per-level arrays and candidate bases are read by every walk: kept in LDS, with the text of every byte of four symbols
     constexpr u32 LDS_LEVELS = 1024;
     __shared__ const uint2* s_pw[LDS_LEVELS];
@@ -1155,9 +1182,41 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
     const u32 b = L.cand_poff[k];
     const u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
     u32 o = pair_off[r];
-    for (u32 q = b; q < e; ++q, ++o) { ids[o] = L.ids[q]; freqs[o] = L.freqs[q]; }
+    const u32 o_first = o, p_first = path_off[r];
+    u64 sumN = fv.d;
+    double sl = 0;
+    bool beyond = false;
+    for (u32 q = b; q < e; ++q, ++o) {
+        const u64 fq = L.freqs[q];
+        ids[o] = L.ids[q]; freqs[o] = fq;
+        sumN += fq;
+        if (fv.ent && !beyond) {
+            if (fq < TERM_TAB) sl += fv.terms[fq]; else beyond = true;
+        }
+    }
+    if (fv.ent) {
+        beyond = beyond || sumN >= LOGN_TAB;
+        u8 verdict = EV_HOST;
+        if (!beyond) {
+            const double en = fv.logn[sumN] - sl / (double)sumN;
+            fv.ent[r] = en;
+            verdict = (fv.emax > 0 && (en < fv.emin || en > fv.emax)) ? EV_DROP : EV_KEEP;
+        }
+        fv.keep[r] = verdict;
+        fv.rel_path[r + fv.chunk] = p_first - fv.pb0;
+        fv.rel_pair[r + fv.chunk] = o_first - fv.qb0;
+        if (r + 1 == rank_hi) {  // the chunk's closing entries
+            fv.rel_path[r + 1 + fv.chunk] = path_off[r + 1] - fv.pb0;
+            fv.rel_pair[r + 1 + fv.chunk] = o - fv.qb0;
+        }
+        const u64 md = __ballot(verdict == EV_DROP), mh = __ballot(verdict == EV_HOST);
+        if ((md | mh) && (threadIdx.x & 63) == (u32)(__ffsll((long long)__ballot(1)) - 1)) {
+            if (md) atomicAdd(fv.counts, (u32)__popcll(md));
+            if (mh) atomicAdd(fv.counts + 1, (u32)__popcll(mh));
+        }
+    }
     u32 v = L.cand_node[k];
-    char* dst = paths + path_off[r];
+    char* dst = paths + p_first;
     u32 l = lvl;
     while (l > 0) {
         const u32 first = ((l - 1) / PW_CHUNK) * PW_CHUNK;  // path position of the chunk's first symbol = level of the ancestor it hangs from
@@ -1481,7 +1540,8 @@ struct DevGrow {  // device buffer that only grows
     ~DevGrow() { if (p) (void)hipFree(p); }
 };
 struct EmitSet {
-    DevGrow dev[5];  // same five arrays on the device: they outlive the arena while the copy stream drains them
+    DevGrow dev[10];  // the five arrays on the device (they outlive the arena while the copy stream drains them), then what the fill
+                      // adds for the host: [5] entropies, [6] verdicts, [7] / [8] offsets relative to the chunks, [9] per-chunk counts
     hipEvent_t ready = nullptr;  // recorded on the copy stream after the last device-to-host copy
     // A large set travels in chunks of consecutive tuples: chunk c is filled, copied and handed to the sink while the
     // following ones are still on their way (the tail of a prefix is one chunk of host work, not the whole set).
@@ -1490,9 +1550,10 @@ struct EmitSet {
     u32 cb[MAX_CHUNKS + 1] = {0};            // tuple boundaries
     hipEvent_t cready[MAX_CHUNKS] = {nullptr};  // chunk c has landed in pinned memory
     int device = 0;
-    PinBuf pin[5];   // path_off, pair_off, ids, freqs, paths (device order = post-order rank)
+    PinBuf pin[10];  // [0] / [1] offsets relative to the chunks (chunk c at [cb[c] + c, cb[c + 1] + c]), [2] ids, [3] freqs, [4] paths (device order
+                     // = post-order rank), [5] entropies, [6] verdicts, [9] per-chunk counts {dropped, left to the host}
+    u64 pb[MAX_CHUNKS + 1] = {0}, qb[MAX_CHUNKS + 1] = {0};  // path byte / pair at which chunk c starts
     RawBuf out[6];   // o_path, o_pair, ent, paths, ids, freqs (kept tuples only)
-    RawBuf ent_all, keep;
     u32 nt = 0;
     bool busy = false;
     ~EmitSet() {
@@ -1556,79 +1617,134 @@ struct HostPool {
     }
 };
 
-static int emit_job(HostPool& pool, EmitSet& E, u32 t_lo, u32 t_hi, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
+// One chunk of a prefix's tuples, landed in pinned memory, to the sink.  The entropies, the emin / emax verdicts and the offsets relative
+// to the chunk arrived with it (tuple_fill_kernel).  What is left for the host: the exact entropy of the few tuples whose frequencies lie
+// beyond the device's tables, with libm as the reference does it, and -- only when tuples were dropped -- moving the kept ones together.
+// With nothing dropped (always so with one sample: its LF-step kernel applied the verdict already, see KEEP_FREQS) the batch IS the
+// pinned arrays and no pass over the tuples runs here at all.
+static int emit_job(HostPool& pool, EmitSet& E, int c, u32 d, double emin, double emax, dsm_tuple_sink sink, void* ctx, u64* n_tuples, u64* n_pairs, double* ms) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    const u32 t_lo = E.cb[c], t_hi = E.cb[c + 1];
     const u32 nt = t_hi - t_lo;  // tuples [t_lo, t_hi) of the set
-    const u32* path_off = (const u32*)E.pin[0].p;
-    const u32* pair_off = (const u32*)E.pin[1].p;
-    const u32* ids = (const u32*)E.pin[2].p;
-    const u64* freqs = (const u64*)E.pin[3].p;
-    const char* paths = (const char*)E.pin[4].p;
-    double* ent = (double*)E.ent_all.ensure((size_t)nt * 8);
-    u8* keep = (u8*)E.keep.ensure(nt);
-    // (offsets rebased to the chunk are written along with the verdicts: they are the batch's offsets if every tuple is kept)
-    u32* o_path = (u32*)E.out[0].ensure(((size_t)nt + 1) * 4);
-    u32* o_pair = (u32*)E.out[1].ensure(((size_t)nt + 1) * 4);
-    const u32 pb0 = path_off[t_lo], qb0 = pair_off[t_lo];
-    unsigned nth = host_threads();
-    if (nt < 65536) nth = 1;
-    const u32 per = (nt + nth - 1) / nth;
-    std::vector<u64> cnt_t(nth + 1, 0), cnt_p(nth + 1, 0), cnt_q(nth + 1, 0);
-    auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; lo += t_lo; hi += t_lo; };
-    const double* terms = term_table();
-    const double* logn = logn_table();
-    auto pass1 = [&](unsigned t) {
-        u32 lo, hi;
-        range(t, lo, hi);
-        u64 kt = 0, kp = 0, kq = 0;
-        for (u32 r = lo; r < hi; ++r) {
-            u64 sumN = d;
-            double sumNlogN = 0;
-            for (u32 q = pair_off[r]; q < pair_off[r + 1]; ++q) {
-                u64 f = freqs[q];
-                sumN += f;
-                sumNlogN += f < TERM_TAB ? terms[f] : (double)(f + 1) * log((double)(f + 1)) / LN2;
+    u32* rel_path = (u32*)E.pin[0].p + t_lo + c;   // nt + 1 entries, the first one 0
+    u32* rel_pair = (u32*)E.pin[1].p + t_lo + c;
+    u32* ids = (u32*)E.pin[2].p + E.qb[c];
+    u64* freqs = (u64*)E.pin[3].p + E.qb[c];
+    char* paths = (char*)E.pin[4].p + E.pb[c];
+    double* ent = (double*)E.pin[5].p + t_lo;
+    u8* keep = (u8*)E.pin[6].p + t_lo;
+    const u32* counts = (const u32*)E.pin[9].p + 2 * c;
+    u64 ndrop = counts[0];
+    if (counts[1]) {  // frequencies of 65536 and more, or a total of 2^20 and more (a few nodes at the top of a pass)
+        for (u8* q = keep; (q = (u8*)memchr(q, EV_HOST, (size_t)(keep + nt - q))) != nullptr; ++q) {  // (memchr: a byte loop over four million verdicts is 4 ms)
+            const u32 r = (u32)(q - keep);
+            const double e = exact_entropy(d, freqs + rel_pair[r], rel_pair[r + 1] - rel_pair[r]);
+            ent[r] = e;
+            const bool k = !(emax > 0 && (e < emin || e > emax));
+            keep[r] = k ? EV_KEEP : EV_DROP;
+            if (!k) ++ndrop;
+        }
+    }
+    if (getenv("DSM_TIMELINE")) { char msg[96]; snprintf(msg, sizeof msg, "nt=%u dropped=%llu host=%u", nt, (unsigned long long)ndrop, counts[1]); timeline("  emitter: verdicts", msg); }
+    u64 W = nt, QW = rel_pair[nt];
+    u32* o_path = rel_path;
+    u32* o_pair = rel_pair;
+    double* o_ent = ent;
+    char* o_paths = paths;
+    u32* o_ids = ids;
+    u64* o_freqs = freqs;
+    constexpr u64 FEW_DROPS = 4096;
+    if (ndrop && ndrop <= FEW_DROPS && ndrop * 64 < nt) {
+        // A handful of tuples dropped among millions (one sample: the few nodes of four million occurrences and more, which only the
+        // host's libm can decide): the runs of kept tuples between them leave as batches of their own, in place -- only the offsets of
+        // a run are rebased to its first tuple (8 bytes per tuple instead of moving the ~55 bytes of every tuple behind the first drop).
+        std::vector<u32> seg;   // runs [seg[2i], seg[2i+1]) of kept tuples
+        {
+            u32 from = 0;
+            for (u8* q = keep; (q = (u8*)memchr(q, EV_DROP, (size_t)(keep + nt - q))) != nullptr; ++q) {
+                const u32 r = (u32)(q - keep);
+                if (r > from) { seg.push_back(from); seg.push_back(r); }
+                from = r + 1;
             }
-            double e = (sumN < LOGN_TAB ? logn[sumN] : log((double)sumN) / LN2) - sumNlogN / (double)sumN;
-            ent[r - t_lo] = e;
-            o_path[r - t_lo] = path_off[r] - pb0;
-            o_pair[r - t_lo] = pair_off[r] - qb0;
-            bool k = !(emax > 0 && (e < emin || e > emax));
-            keep[r - t_lo] = k;
-            if (k) { ++kt; kp += path_off[r + 1] - path_off[r]; kq += pair_off[r + 1] - pair_off[r]; }
+            if (nt > from) { seg.push_back(from); seg.push_back(nt); }
         }
-        cnt_t[t + 1] = kt; cnt_p[t + 1] = kp; cnt_q[t + 1] = kq;
-    };
-    auto run_all = [&](auto&& fn) { pool.run(nth, fn); };
-    run_all(pass1);
-    for (unsigned t = 0; t < nth; ++t) { cnt_t[t + 1] += cnt_t[t]; cnt_p[t + 1] += cnt_p[t]; cnt_q[t + 1] += cnt_q[t]; }
-    const u64 W = cnt_t[nth], PW = cnt_p[nth], QW = cnt_q[nth];
-    // Nothing dropped (one sample: the device applied the exact entropy verdict already, see KEEP_FREQS): the tuples stay where the
-    // copy engine put them -- only the offsets are rebased to the chunk -- instead of being moved together (3.9 GB per pass at the
-    // benchmark size, 4-15 ms of a pass's 180 and most of its run-to-run spread).
-    const bool in_place = W == nt;
-    double* o_ent = in_place ? ent : (double*)E.out[2].ensure(W * 8 + 8);
-    char* o_paths = in_place ? const_cast<char*>(paths) + path_off[t_lo] : (char*)E.out[3].ensure(PW + 1);
-    u32* o_ids = in_place ? const_cast<u32*>(ids) + pair_off[t_lo] : (u32*)E.out[4].ensure(QW * 4 + 4);
-    u64* o_freqs = in_place ? const_cast<u64*>(freqs) + pair_off[t_lo] : (u64*)E.out[5].ensure(QW * 8 + 8);
-    auto pass2 = [&](unsigned t) {
-        u32 lo, hi;
-        range(t, lo, hi);
-        u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
-        for (u32 r = lo; r < hi; ++r) {
-            if (!keep[r - t_lo]) continue;
-            u32 pb = path_off[r], pl = path_off[r + 1] - pb, qb = pair_off[r], ql = pair_off[r + 1] - qb;
-            o_path[w] = (u32)pw; o_pair[w] = (u32)qw; o_ent[w] = ent[r - t_lo];
-            memcpy(o_paths + pw, paths + pb, pl);
-            memcpy(o_ids + qw, ids + qb, (size_t)ql * 4);
-            memcpy(o_freqs + qw, freqs + qb, (size_t)ql * 8);
-            ++w; pw += pl; qw += ql;
+        const size_t ns = seg.size() / 2;
+        std::vector<u32> bp(ns), bq(ns);
+        for (size_t i = 0; i < ns; ++i) { bp[i] = rel_path[seg[2 * i]]; bq[i] = rel_pair[seg[2 * i]]; }
+        unsigned nth = host_threads();
+        if (nt < 65536) nth = 1;
+        const u32 per = (nt + nth - 1) / nth;
+        auto rebase = [&](unsigned t) {   // entries lo .. hi - 1 of this thread; a run owns the entries seg[2i] .. seg[2i+1] (its closing one included)
+            const u32 lo = t * per < nt ? t * per : nt, hi = t + 1 == nth ? nt + 1 : (lo + per < nt ? lo + per : nt);
+            size_t i = (size_t)(std::upper_bound(seg.begin(), seg.end(), lo) - seg.begin());  // first boundary beyond lo
+            i = i / 2;  // the run that contains lo, or the next one
+            if (i > 0 && lo <= seg[2 * (i - 1) + 1]) --i;
+            for (; i < ns && seg[2 * i] < hi; ++i) {
+                const u32 a = seg[2 * i] > lo ? seg[2 * i] : lo, b = seg[2 * i + 1] + 1 < hi ? seg[2 * i + 1] + 1 : hi;
+                const u32 sp_ = bp[i], sq_ = bq[i];
+                if (!sp_ && !sq_) continue;
+                for (u32 r = a; r < b; ++r) { rel_path[r] -= sp_; rel_pair[r] -= sq_; }
+            }
+        };
+        pool.run(nth, rebase);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        *ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+        for (size_t i = 0; i < ns; ++i) {
+            const u32 a = seg[2 * i], n = seg[2 * i + 1] - a;
+            *n_tuples += n;
+            *n_pairs += rel_pair[a + n];
+            if (!sink) continue;
+            dsm_tuple_batch bt;
+            bt.ntuples = n;
+            bt.path_off = rel_path + a; bt.path_bytes = paths + bp[i]; bt.entropy = ent + a;
+            bt.pair_off = rel_pair + a; bt.ids = ids + bq[i]; bt.freqs = freqs + bq[i];
+            if (sink(ctx, &bt)) return 1;
         }
-    };
-    if (!in_place) run_all(pass2);
-    o_path[W] = (u32)PW;
-    o_pair[W] = (u32)QW;
+        return 0;
+    }
+    if (ndrop) {  // the kept tuples move together (ranges of the chunk by the pool's threads: count, then move)
+        unsigned nth = host_threads();
+        if (nt < 65536) nth = 1;
+        const u32 per = (nt + nth - 1) / nth;
+        std::vector<u64> cnt_t(nth + 1, 0), cnt_p(nth + 1, 0), cnt_q(nth + 1, 0);
+        auto range = [&](unsigned t, u32& lo, u32& hi) { lo = t * per < nt ? t * per : nt; hi = lo + per < nt ? lo + per : nt; };
+        auto pass1 = [&](unsigned t) {
+            u32 lo, hi;
+            range(t, lo, hi);
+            u64 kt = 0, kp = 0, kq = 0;
+            for (u32 r = lo; r < hi; ++r)
+                if (keep[r] == EV_KEEP) { ++kt; kp += rel_path[r + 1] - rel_path[r]; kq += rel_pair[r + 1] - rel_pair[r]; }
+            cnt_t[t + 1] = kt; cnt_p[t + 1] = kp; cnt_q[t + 1] = kq;
+        };
+        pool.run(nth, pass1);
+        for (unsigned t = 0; t < nth; ++t) { cnt_t[t + 1] += cnt_t[t]; cnt_p[t + 1] += cnt_p[t]; cnt_q[t + 1] += cnt_q[t]; }
+        W = cnt_t[nth]; QW = cnt_q[nth];
+        const u64 PW = cnt_p[nth];
+        o_path = (u32*)E.out[0].ensure((W + 1) * 4);
+        o_pair = (u32*)E.out[1].ensure((W + 1) * 4);
+        o_ent = (double*)E.out[2].ensure(W * 8 + 8);
+        o_paths = (char*)E.out[3].ensure(PW + 1);
+        o_ids = (u32*)E.out[4].ensure(QW * 4 + 4);
+        o_freqs = (u64*)E.out[5].ensure(QW * 8 + 8);
+        auto pass2 = [&](unsigned t) {
+            u32 lo, hi;
+            range(t, lo, hi);
+            u64 w = cnt_t[t], pw = cnt_p[t], qw = cnt_q[t];
+            for (u32 r = lo; r < hi; ++r) {
+                if (keep[r] != EV_KEEP) continue;
+                const u32 pb = rel_path[r], pl = rel_path[r + 1] - pb, qb = rel_pair[r], ql = rel_pair[r + 1] - qb;
+                o_path[w] = (u32)pw; o_pair[w] = (u32)qw; o_ent[w] = ent[r];
+                memcpy(o_paths + pw, paths + pb, pl);
+                memcpy(o_ids + qw, ids + qb, (size_t)ql * 4);
+                memcpy(o_freqs + qw, freqs + qb, (size_t)ql * 8);
+                ++w; pw += pl; qw += ql;
+            }
+        };
+        pool.run(nth, pass2);
+        o_path[W] = (u32)PW;
+        o_pair[W] = (u32)QW;
+    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     *ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
     *n_tuples += W;
@@ -1825,10 +1941,12 @@ struct Emitter {
             int rc = 0;
             for (int c = 0; c < set[k].nchunk && !rc; ++c) {
                 rc = set[k].cready[c] && hipEventSynchronize(set[k].cready[c]) != hipSuccess ? 1 : 0;  // the chunk has landed (text mode: has been filled)
+                timeline("  emitter: chunk landed");
                 if (!rc && set[k].cb[c + 1] > set[k].cb[c]) {
                     if (text_sink) rc = text_job(set[k], set[k].cb[c], set[k].cb[c + 1], &t, &pq, &m);
-                    else rc = emit_job(pool, set[k], set[k].cb[c], set[k].cb[c + 1], d, emin, emax, sink, ctx, &t, &pq, &m);
+                    else rc = emit_job(pool, set[k], c, d, emin, emax, sink, ctx, &t, &pq, &m);
                 }
+                timeline("  emitter: chunk through the sink");
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -2817,6 +2935,7 @@ class Engine {
             if (L.size() > 60000) return fail(DSM_E_CAPACITY, "trie deeper than 60000 levels");
         }
         const u32 nlev = (u32)L.size();  // levels 0..nlev-1, level l holds the nodes of depth l
+        timeline("levels done", prefix.c_str());
         if (int rc = flush_pending()) return rc;  // (a prefix that never got wide or deep)
 
         bool ready = false;
@@ -2854,7 +2973,9 @@ class Engine {
         }
 
         DSM_HIP(hipEventRecord(ev1, st));
+        timeline("finish queued", prefix.c_str());
         DSM_HIP(hipStreamSynchronize(st));
+        timeline("device done", prefix.c_str());
         float ms = 0;
         DSM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         stats.device_ms += ms;
@@ -3022,12 +3143,32 @@ class Engine {
         char* d_paths = (char*)E.dev[4].p;
         emitter.text_sink = text_sink_;
         const bool text_mode = text_sink_ != nullptr;  // the emitter formats the chunks on the card: no binary copies, no pinned arrays
+        FillVerdict fv;
+        memset(&fv, 0, sizeof fv);
         if (!text_mode) {
-            if (int rc = E.pin[0].ensure(((size_t)nt + 1) * 4)) return rc;
-            if (int rc = E.pin[1].ensure(((size_t)nt + 1) * 4)) return rc;
+            const size_t nrel = (size_t)nt + EmitSet::MAX_CHUNKS + 1;
+            if (int rc = E.pin[0].ensure(nrel * 4)) return rc;
+            if (int rc = E.pin[1].ensure(nrel * 4)) return rc;
             if (int rc = E.pin[2].ensure((size_t)npairs * 4)) return rc;
             if (int rc = E.pin[3].ensure((size_t)npairs * 8)) return rc;
             if (int rc = E.pin[4].ensure((size_t)path_bytes)) return rc;
+            if (int rc = E.pin[5].ensure((size_t)nt * 8)) return rc;
+            if (int rc = E.pin[6].ensure((size_t)nt)) return rc;
+            if (int rc = E.pin[9].ensure(2 * EmitSet::MAX_CHUNKS * sizeof(u32))) return rc;
+            if (int rc = E.dev[5].ensure((size_t)nt * 8)) return rc;
+            if (int rc = E.dev[6].ensure((size_t)nt)) return rc;
+            if (int rc = E.dev[7].ensure(nrel * 4)) return rc;
+            if (int rc = E.dev[8].ensure(nrel * 4)) return rc;
+            if (int rc = E.dev[9].ensure(2 * EmitSet::MAX_CHUNKS * sizeof(u32))) return rc;
+            if (!d_terms) {  // the tables of the exact entropy, once per miner (8.5 MB)
+                if (int rc = dalloc(d_terms, (size_t)TERM_TAB)) return rc;
+                if (int rc = dalloc(d_logn, (size_t)LOGN_TAB)) return rc;
+                DSM_HIP(hipMemcpyAsync(d_terms, term_table(), (size_t)TERM_TAB * 8, hipMemcpyHostToDevice, st));
+                DSM_HIP(hipMemcpyAsync(d_logn, logn_table(), (size_t)LOGN_TAB * 8, hipMemcpyHostToDevice, st));
+            }
+            DSM_HIP(hipMemsetAsync(E.dev[9].p, 0, 2 * EmitSet::MAX_CHUNKS * sizeof(u32), st));
+            fv.ent = (double*)E.dev[5].p; fv.keep = (u8*)E.dev[6].p; fv.rel_path = (u32*)E.dev[7].p; fv.rel_pair = (u32*)E.dev[8].p;
+            fv.terms = d_terms; fv.logn = d_logn; fv.d = d; fv.emin = prm.emin; fv.emax = prm.emax;
         }
         E.nchunk = cbs.n;
         // One fill per chunk of output ranks (its threads follow the levels, not the output order: every launch looks at all candidates and
@@ -3040,7 +3181,9 @@ class Engine {
         // waited for a compute unit (measured: 300-1500 us for a one-workgroup LF-step launch that takes 10 us alone; 9 ms per pass).
         for (int c = 0; c < cbs.n; ++c) {
             const u32 t0 = cbs.tb[c], t1 = cbs.tb[c + 1];
-            hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs, t0, t1);
+            fv.chunk = (u32)c; fv.pb0 = h_totals[16 + 2 * c]; fv.qb0 = h_totals[17 + 2 * c];
+            fv.counts = text_mode ? nullptr : (u32*)E.dev[9].p + 2 * c;
+            hipLaunchKernelGGL(tuple_fill_kernel, grid_for(nt), dim3(256), 0, st, nt, nlev, d_lv, path_off, pair_off, d_paths, d_ids, d_freqs, t0, t1, fv);
             DSM_HIP(hipGetLastError());
             E.cb[c] = t0; E.cb[c + 1] = t1;
             if (!E.cready[c]) DSM_HIP(hipEventCreateWithFlags(&E.cready[c], hipEventDisableTiming));
@@ -3068,8 +3211,6 @@ class Engine {
         pend.E = nullptr;
         pend.submit = false;
         DSM_HIP(hipSetDevice(device));
-        const u32* path_off = (const u32*)E.dev[0].p;
-        const u32* pair_off = (const u32*)E.dev[1].p;
         const u32* d_ids = (const u32*)E.dev[2].p;
         const u64* d_freqs = (const u64*)E.dev[3].p;
         const char* d_paths = (const char*)E.dev[4].p;
@@ -3082,9 +3223,15 @@ class Engine {
             }
             DSM_HIP(hipStreamWaitEvent(copy_stream, chunk_filled[c], 0));
             const u64 pb0 = pend.off[2 * c], qb0 = pend.off[2 * c + 1], pb1 = pend.off[2 * (c + 1)], qb1 = pend.off[2 * (c + 1) + 1];
-            // boundary entries are shared by neighbouring chunks: both copy the same value
-            DSM_HIP(hipMemcpyAsync((u32*)E.pin[0].p + t0, path_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
-            DSM_HIP(hipMemcpyAsync((u32*)E.pin[1].p + t0, pair_off + t0, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+            // offsets relative to the chunk (its own closing entry included), entropies, verdicts, the chunk's counts
+            DSM_HIP(hipMemcpyAsync((u32*)E.pin[0].p + t0 + c, (const u32*)E.dev[7].p + t0 + c, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+            DSM_HIP(hipMemcpyAsync((u32*)E.pin[1].p + t0 + c, (const u32*)E.dev[8].p + t0 + c, ((size_t)(t1 - t0) + 1) * 4, hipMemcpyDeviceToHost, copy_stream));
+            if (t1 > t0) {
+                DSM_HIP(hipMemcpyAsync((double*)E.pin[5].p + t0, (const double*)E.dev[5].p + t0, (size_t)(t1 - t0) * 8, hipMemcpyDeviceToHost, copy_stream));
+                DSM_HIP(hipMemcpyAsync((u8*)E.pin[6].p + t0, (const u8*)E.dev[6].p + t0, (size_t)(t1 - t0), hipMemcpyDeviceToHost, copy_stream));
+            }
+            DSM_HIP(hipMemcpyAsync((u32*)E.pin[9].p + 2 * c, (const u32*)E.dev[9].p + 2 * c, 2 * sizeof(u32), hipMemcpyDeviceToHost, copy_stream));
+            E.pb[c] = pb0; E.qb[c] = qb0;
             if (qb1 > qb0) {
                 DSM_HIP(hipMemcpyAsync((u32*)E.pin[2].p + qb0, d_ids + qb0, (qb1 - qb0) * 4, hipMemcpyDeviceToHost, copy_stream));
                 DSM_HIP(hipMemcpyAsync((u64*)E.pin[3].p + qb0, d_freqs + qb0, (qb1 - qb0) * 8, hipMemcpyDeviceToHost, copy_stream));
@@ -3097,13 +3244,18 @@ class Engine {
         return 0;
     }
     hipStream_t copy_stream = nullptr;
+    double* d_terms = nullptr;   // device copies of the entropy tables (entropy_tables.h), made when the first tuples are filled
+    double* d_logn = nullptr;
     hipEvent_t fill_done = nullptr;
     hipEvent_t chunk_filled[EmitSet::MAX_CHUNKS] = {nullptr};
 
     // wait for the emitter and fold its counters into stats
     int finish_emits() {
+        timeline("finish_emits");
         if (int rc = flush_pending()) return rc;
+        timeline("last set submitted");
         emitter.drain();
+        timeline("emitter drained");
         std::lock_guard<std::mutex> lk(emitter.mu);
         stats.tuples += emitter.tuples; stats.pairs += emitter.pairs; stats.host_ms += emitter.ms;
         emitter.tuples = emitter.pairs = 0;
@@ -3327,6 +3479,7 @@ struct MinerT : MinerBase {
         memset(&e.stats, 0, sizeof e.stats);
         e.text_sink_ = xs;
         int rc = 0;
+        timeline("call begins");
         if (e.stream_mode) { e.sout.sink = bs; e.sout.psink = ps; e.sout.ctx = ctx; }
         for (int k = 0; k < n && !rc; ++k) {
             const bool mine = e.owner_mode ? e.is_owner : (!e.prm.emit_owner_only || e.world <= 1 || (k % e.world) == e.rank);
