@@ -2059,6 +2059,8 @@ class Engine {
     u64** d_splane_tab = nullptr;
     bool spec_mode = false;     // single sample: the next level's LF-step launch is queued before the host has seen the level (see ExpandArgs::dyn)
     u32* d_dyn = nullptr;       // [0] width [1] frequency class of the level the last publish kernel announced
+    bool dense_mode = true;     // DSM_DENSE=0: the sparse sweep on every level (A/B runs)
+    u32 dense_min = 1u << 18;   // DSM_DENSE_MIN: narrowest level the dense sweep takes
     bool pack_columns = true;   // levels whose frequencies are all below 512: one 16-bit column word per node (DSM_PACK=0 turns it off)
     bool batch_mode = true;     // several samples: one launch per level for up to BATCH_MAX of this process's, handles derived in the kernel
     bool self_mode = false;     // = several samples, index mode, batch_mode: no handle tables (see expand_tile, SELF)
@@ -2171,6 +2173,8 @@ class Engine {
         DSM_HIP(hipMemGetInfo(&free_b, &total_b));
         if (const char* e = getenv("DSM_BATCH")) batch_mode = atoi(e) != 0;
         if (const char* e = getenv("DSM_PACK")) pack_columns = atoi(e) != 0;
+        if (const char* e = getenv("DSM_DENSE")) dense_mode = atoi(e) != 0;
+        if (const char* e = getenv("DSM_DENSE_MIN")) dense_min = (u32)atol(e);
         spec_mode = d == 1 && !trie_mode && !multi;
         if (const char* e = getenv("DSM_SPEC")) spec_mode = spec_mode && atoi(e) != 0;
         if (spec_mode) { if (int rc = dalloc(d_dyn, (size_t)4)) return rc; }
@@ -2604,6 +2608,9 @@ class Engine {
                 stats.expand_column_bytes += (u64)F * colb;
                 LfConfig lc;
                 lc.wide_pos = sizeof(P) == 8; lc.fmt_in = fmt_in; lc.fmt_out = w16;
+                // several samples: a sample holds a fraction of the union level (half with eight 1-Gbase samples, a fifth with 64): on the
+                // levels wide enough to keep every wave busy with items, each sample's own nodes are packed into full tiles (expand.hip)
+                lc.dense = dense_mode && self_mode && fmt_in && F >= dense_min;
                 // record formats: this level's records are compact iff its parent level was narrow (fmt_in), the children's iff this one is
                 if (self_mode) {  // several samples: one launch for up to BATCH_MAX of this process's
                     if (nb < BATCH_MAX && s + 1 < nlocal) continue;

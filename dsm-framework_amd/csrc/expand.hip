@@ -24,9 +24,11 @@ constexpr bool LF_DYNAMIC = true;
 #endif
 // (INC: the level's records are compact.  The wide levels -- the few at the top of a prefix, a handful of tiles each -- run with two
 // waves per SIMD: their interval-major child loop keeps four children's state in registers.)
-template <typename P, bool INC = true>
+// (DENSE: the sweep of one sample among several, its live nodes packed into full tiles -- see expand_sweep; three waves per SIMD: its
+// queue and plane words take the LDS a fourth wave's staging area would)
+template <typename P, bool INC = true, bool DENSE = false>
 struct LfShape {
-    static constexpr int WAVES_PER_SIMD = !INC ? 2 : (sizeof(P) == 4 ? 4 : 3);   // 256 / 128 / 168 vector registers
+    static constexpr int WAVES_PER_SIMD = !INC ? 2 : (DENSE ? 3 : (sizeof(P) == 4 ? 4 : 3));   // 256 / 128 / 168 vector registers
 #ifdef DSM_LF_WPB
     static constexpr int WPB = DSM_LF_WPB;
 #else
@@ -298,17 +300,38 @@ __device__ __forceinline__ u32 self_handle(u32 slot, u64 plane, u32 seg) {
 }
 __device__ __forceinline__ size_t self_plane_index(u32 slot) { return slot != DEAD ? (size_t)(slot >> 8) * 4 + (slot & 3u) : (size_t)0; }
 
-template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF, int WPB>
+// DENSE (one sample among several): the 64 lanes hold 64 consecutive nodes THIS SAMPLE HAS, wherever they sit in the union level -- a
+// union tile's nodes may be spread over two dense tiles, a dense tile may span many union tiles.  What depended on "lane j = node j of
+// union tile t" is carried per lane: the node's place in the union level (its column entry), and, for the children's handles
+// c * seg + 64 * T + (parents with a child c before it in union tile T), the lanes of the same union tile (they are neighbours) plus
+// what the previous dense tile held of the first one.  The planes of the union tiles are put together in LDS, bit by bit.
+#ifndef DSM_DENSE_STEP32
+#define DSM_DENSE_STEP32 4   // union tiles per producer step, 32-bit positions (A/B builds: -DDSM_DENSE_STEP32=6)
+#endif
+constexpr u32 DENSE_Q = 512;       // queue entries per wave (a ring: a tile being prefetched, a tile in waiting, a producer step of up to four union tiles)
+constexpr u32 DENSE_ITEM_MAX = 32; // union tiles per work item (ExpandArgs::item_tiles: smaller on smaller levels)
+constexpr u32 DENSE_LDS_WORDS = DENSE_Q + DENSE_Q / 2 + DENSE_ITEM_MAX * 4 * 2;  // u32 per wave: queue (handles; places inside the item, 16 bits), the item's plane words
+struct DenseTile {
+    u32 iu;         // per lane: the node's place in the union level
+    u32 rnext;      // per lane: handle of the lane's node in the wave's next dense tile (DEAD: none)
+    u64* lpl;       // LDS: plane words of the item's union tiles, [tile - T0][4]
+    u32 T0;         // first union tile of the item
+    u32 carry[4];   // in / out (wave-uniform): children c among the nodes of union tile lastT that earlier dense tiles held
+    u32 lastT;      // in / out: union tile of the last node of the previous dense tile (~0: none)
+};
+
+template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF, int WPB, bool DENSE = false>
 __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, uint4* wl, const u32* __restrict__ rp, const P* __restrict__ rec,
                                             P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                             u8* __restrict__ pl, const ExpandArgs& a, const u32 t, TileSeq<WPB>& seq, u32& tfar, const u32 ntile,
                                             const RecHead<P, INC>& hc, RecHead<P, INC>& hn, u32& rn, ExpandAcc& acc,
-                                            const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab, const u32 cost_pack) {
+                                            const u64* __restrict__ pplane, SelfState* ss, const u32* __restrict__ keeptab, const u32 cost_pack,
+                                            DenseTile* dt = nullptr) {
     const int lane = threadIdx.x & 63;
     const u64 lt = (1ull << lane) - 1;
     const size_t cap = a.cap, capi = a.cap_in;   // handle spaces of the children's records and of this level's
-    const u32 i = t * 64 + lane;
-    const u32 drawn = seq.issue();  // (the wave's tile after next, or three ahead: taken where its handles are requested)
+    const u32 i = DENSE ? dt->iu : t * 64 + lane;
+    const u32 drawn = DENSE ? 0u : seq.issue();  // (the wave's tile after next, or three ahead: taken where its handles are requested)
     NodeIn<P> nd;
     decode_head(hc, nd);
     const bool live = nd.live;
@@ -373,8 +396,9 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         }
         // ---- the pipeline: heads of the next tile, handles of the one after (younger than the block loads, so waiting for
         // the blocks leaves them in flight) ----
-        tfar = seq.take(drawn);
-        {
+        if (DENSE) load_head<P>(rec, capi, dt->rnext, hn);
+        else {
+            tfar = seq.take(drawn);
             const u32 ifar = tfar * 64 + lane;
             const bool infar = tfar < ntile && ifar < a.F;
             if (SELF) {
@@ -486,15 +510,38 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     u64 bal[4];
     u32 qa[4];  // handle of this lane's child with symbol c
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        bal[c] = __ballot((present >> c) & 1u);
-        qa[c] = (u32)c * a.seg + t * 64 + (u32)__popcll(bal[c] & lt);
-    }
-    if (lane < 4) {
-        const u64 b = DSM_PICK(bal, lane);
-        if (!(a.symbol_phase & 8u)) splane[(size_t)t * 4 + lane] = b;
-        const u32 nb = (u32)__popcll(b);
-        if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
+    for (int c = 0; c < 4; ++c) bal[c] = __ballot((present >> c) & 1u);
+    if constexpr (DENSE) {
+        const u64 lv = __ballot(live);                       // (the live lanes are the first ones: only a wave's last tile of an item is short)
+        const u32 T = live ? (i >> 6) : 0xFFFFFFFFu;
+        const u32 Tp = __shfl_up(T, 1, 64);
+        const u64 bnd = __ballot(lane == 0 || T != Tp);      // first lanes of the runs of one union tile
+        const u32 gs = 63u - (u32)__clzll((long long)(bnd & (lt | (1ull << lane))));   // first lane of this lane's run
+        const u64 gmask = lt & ~((1ull << gs) - 1ull);       // the lanes of the run before this one
+        const u32 Tfirst = (u32)__builtin_amdgcn_readfirstlane((int)T);
+        const bool cont = dt->lastT == Tfirst;               // the first run continues a union tile the previous dense tile ended in
+        const u32 nl = (u32)__popcll(lv);
+        const u32 last = nl ? nl - 1u : 0u;
+        const u32 Tlast = (u32)__builtin_amdgcn_readlane((int)T, (int)last);
+        const u32 gs_last = (u32)__builtin_amdgcn_readlane((int)gs, (int)last);
+        const u64 lastrun = lv & ~((1ull << gs_last) - 1ull);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32 cin = cont ? dt->carry[c] : 0u;
+            qa[c] = (u32)c * a.seg + (i & ~63u) + (u32)__popcll(bal[c] & gmask) + (T == Tfirst ? cin : 0u);
+            if ((present >> c) & 1u) atomicOr((unsigned long long*)&dt->lpl[(size_t)((i >> 6) - dt->T0) * 4 + c], 1ull << (i & 63u));
+            dt->carry[c] = (u32)__popcll(bal[c] & lastrun) + (Tlast == Tfirst ? cin : 0u);
+        }
+        if (nl) dt->lastT = Tlast;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qa[c] = (u32)c * a.seg + t * 64 + (u32)__popcll(bal[c] & lt);
+        if (lane < 4) {
+            const u64 b = DSM_PICK(bal, lane);
+            if (!(a.symbol_phase & 8u)) splane[(size_t)t * 4 + lane] = b;
+            const u32 nb = (u32)__popcll(b);
+            if (cnt && nb) atomicAdd(cnt + (size_t)lane * a.nbp + (t >> 2), nb);
+        }
     }
     // EnumerateQuery::leftChar, EnumerateQuery.cpp:77-103: 0='0' 1..4=A,C,G,T 5='N' (the letter is the LAST non-empty base)
     bool matches = (ne > 0 && nd.e0min == sp && nd.e0max == ep) || (ne > 1 && nd.e1min == sp && nd.e1max == ep);
@@ -670,7 +717,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             if (e >= ne1) { e = 0; ++j; }
         }
     }
-    if (i < a.F) {
+    if (DENSE ? live : i < a.F) {   // (DENSE: the entries of the nodes the sample does not have were cleared by the sweep's producer)
         // this node's column entry: its frequency in this sample (0 = absent), which children survive, its left char
         if (a.w16 == 2) {
             reinterpret_cast<u16*>(valf)[(size_t)i * a.cstride] = live ? (u16)((u32)(ep - sp + 1) | ((present | (mycode << 4)) << 9)) : (u16)0;
@@ -694,12 +741,19 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
 
 // One sample's LF-step sweep over a level: the body of expand_kernel (one sample per launch) and of expand_batch_kernel.
 // tile_ctr: the workgroup's tile counter in LDS, zero when the sweep starts (the caller's barrier).
-template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF>
+// DENSE (SELF, compact records): with d samples a sample holds a fraction of the union level's nodes -- half of them with eight
+// 1-Gbase samples, a fifth with 64 -- and a sweep over the union tiles runs its instruction stream for the absent ones as well.  Here
+// a wave takes an ITEM of consecutive union tiles, a PRODUCER step turns two of them at a time into handles (slots and parent
+// planes, as the sparse sweep does), clears the column entries of the absent nodes and appends the present ones -- handle and place
+// in the union level -- to a queue in LDS; whenever the queue holds two tiles' worth (or the item is used up) the wave runs the
+// tile body on the next 64 queued nodes, with the heads of the 64 after them requested inside it as before.  An item's plane words
+// are put together in LDS and written when it is done.  Nothing crosses items: their last tile is the only short one.
+template <typename P, bool ONESB, bool INC, bool OUTC, bool SELF, bool DENSE = false>
 __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4* parked, u32* tile_ctr, const u32* __restrict__ rp, const P* __restrict__ rec,
                                              P* __restrict__ out, u64* __restrict__ splane, u32* __restrict__ cnt, P* __restrict__ valf,
                                              u8* __restrict__ pl, const ExpandArgs& a, u64* __restrict__ counters,
-                                             unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane) {
-    constexpr int WPB = LfShape<P, INC>::WPB;
+                                             unsigned long long* __restrict__ childmax, const u64* __restrict__ pplane, u32* dense_lds = nullptr) {
+    constexpr int WPB = LfShape<P, INC, DENSE>::WPB;
     uint4* wl = parked + (threadIdx.x >> 6) * WAVE_LDS_WORDS;
     if (!ONESB) {
         const u32 nsb4 = (u32)((ix.n >> SB_SHIFT) + 1) * 4;
@@ -718,7 +772,105 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
 #endif
     TileSeq<WPB> seq;
     seq.ctr = tile_ctr; seq.G = gridDim.x; seq.b = blockIdx.x; seq.stride = gridDim.x * WPB;
-    u32 tA, tB, tC = ~0u;
+    u32 tA = ~0u, tB = ~0u, tC = ~0u;
+    if constexpr (DENSE) {
+        static_assert(SELF && INC && LF_DYNAMIC, "the dense sweep is the several-sample sweep over compact records");
+        u32* qh = dense_lds + (threadIdx.x >> 6) * DENSE_LDS_WORDS;   // queue: handles
+        unsigned short* qi = reinterpret_cast<unsigned short*>(qh + DENSE_Q);   //  places in the union level, relative to the item's first
+        u64* lpl = reinterpret_cast<u64*>(qh + DENSE_Q + DENSE_Q / 2);          // plane words of the item's union tiles
+        const u32 item = a.item_tiles;
+        const u32 nitem = (ntile + item - 1) / item;
+        u32 dummy_t = 0, dummy_r = DEAD;
+        DenseTile dt;
+        dt.lpl = lpl;
+        for (u32 it = seq.next(); it < nitem; it = seq.next()) {
+            const u32 T0 = it * item, T1 = T0 + item < ntile ? T0 + item : ntile;
+            tA = 0;  // (DSM_CLOCK_PROBE: the wave had work)
+            for (u32 w = (u32)lane; w < item * 4; w += 64) lpl[w] = 0;
+            dt.T0 = T0; dt.lastT = ~0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dt.carry[c] = 0;
+            u32 qhead = 0, qtail = 0;
+            bool have_heads = false;
+            RecHead<P, INC> hA, hB;
+            // The producer is a pipeline of its own, two steps deep, so that a tile body hides both of its round trips: the slots of
+            // step k + 2 are requested when the parent planes of step k + 1 are (their slots have arrived) and step k is queued (its
+            // planes have).  chunkS: first union tile of the next slot request; chunkQ: of the step that is queued next.
+            // (Measured and not kept: starting the NEXT item's first requests while the last tiles of an item are worked on, so that an
+            // item start costs one round trip instead of four -- the state that has to live outside the item loop takes 16 more
+            // registers, and the LF-step sweeps of eight samples went from 795-808 to 846-860 ms per pass.)
+            constexpr u32 STEP = sizeof(P) == 4 ? (u32)DSM_DENSE_STEP32 : 2u;
+            u32 s1[STEP], s2[STEP];   // slots of the step whose slots / planes are on their way
+            u64 p2[STEP];             // parent planes of the second
+            u32 chunkS = T0, chunkQ = T0;
+            auto request_slots = [&](u32* sl) {
+#pragma unroll
+                for (u32 b = 0; b < STEP; ++b) {
+                    const u32 iu = (chunkS + b) * 64 + lane;
+                    const bool in = chunkS + b < T1 && iu < a.F;
+                    const u32 v = rp[in ? iu : 0u];
+                    sl[b] = in ? v : DEAD;
+                }
+                chunkS += STEP;
+            };
+            auto advance = [&]() {
+                // queue the step whose planes have arrived
+#pragma unroll
+                for (u32 b = 0; b < STEP; ++b) {
+                    const u32 iu = (chunkQ + b) * 64 + lane;
+                    const bool in = chunkQ + b < T1 && iu < a.F;
+                    const u32 h = self_handle(s2[b], p2[b], a.seg_in);
+                    const bool has = h != DEAD;
+                    if (in && !has) {   // the sample does not hold the node: an empty column entry
+                        if (a.w16 == 2) reinterpret_cast<u16*>(valf)[(size_t)iu * a.cstride] = (u16)0;
+                        else {
+                            if (a.w16) reinterpret_cast<u16*>(valf)[iu] = (u16)0;
+                            else valf[iu] = (P)0;
+                            pl[iu] = (u8)0;
+                        }
+                    }
+                    const u64 m = __ballot(has);
+                    if (has) {
+                        const u32 pos = (qtail + lf_bits_below_lane(m)) & (DENSE_Q - 1);
+                        qh[pos] = h; qi[pos] = (unsigned short)(iu - T0 * 64);
+                    }
+                    qtail += (u32)__popcll(m);
+                }
+                chunkQ += STEP;
+                // the next step's planes (its slots have arrived), the slots of the one after
+#pragma unroll
+                for (u32 b = 0; b < STEP; ++b) { s2[b] = s1[b]; p2[b] = pplane[self_plane_index(s1[b])]; }
+                request_slots(s1);
+            };
+            // prime: step 0's planes and step 1's slots on their way
+            request_slots(s2);
+#pragma unroll
+            for (u32 b = 0; b < STEP; ++b) p2[b] = pplane[self_plane_index(s2[b])];
+            request_slots(s1);
+            // one step: the queue is topped up, then one dense tile is worked on with its heads in hc (the next one's go to hn)
+            auto step = [&](RecHead<P, INC>& hc, RecHead<P, INC>& hn) -> bool {
+                while (qtail - qhead < 128u && chunkQ < T1) advance();
+                const u32 qc = qtail - qhead;
+                if (qc == 0) return false;
+                const u32 n = qc < 64u ? qc : 64u, nn = qc - n < 64u ? qc - n : 64u;
+                asm volatile("" ::: "memory");  // (the queue entries other lanes wrote)
+                dt.iu = (u32)lane < n ? T0 * 64 + (u32)qi[(qhead + lane) & (DENSE_Q - 1)] : 0u;
+                if (!have_heads) {   // the item's first tile: its heads were not requested by a tile before it
+                    const u32 hv = (u32)lane < n ? qh[(qhead + lane) & (DENSE_Q - 1)] : DEAD;
+                    load_head<P>(rec, a.cap_in, hv, hc);
+                    have_heads = true;
+                }
+                dt.rnext = (u32)lane < nn ? qh[(qhead + n + lane) & (DENSE_Q - 1)] : DEAD;
+                expand_tile<P, ONESB, INC, OUTC, SELF, WPB, true>(ix, sbl, wl, rp, rec, out, splane, cnt, valf, pl, a, 0u, seq, dummy_t, ntile, hc, hn, dummy_r, acc, pplane,
+                                                                  nullptr, keeptab, cost_pack, &dt);
+                qhead += n;
+                return true;
+            };
+            while (step(hA, hB) && step(hB, hA)) {}
+            asm volatile("" ::: "memory");
+            for (u32 w = (u32)lane; w < (T1 - T0) * 4; w += 64) splane[(size_t)T0 * 4 + w] = lpl[w];
+        }
+    } else {
     if (LF_DYNAMIC) { tA = seq.next(); tB = seq.next(); if (SELF) tC = seq.next(); }
     else {
         tA = gw; tB = ~gw < seq.stride ? ~0u : gw + seq.stride;
@@ -759,6 +911,7 @@ __device__ __forceinline__ void expand_sweep(const DevIndex& ix, u64* sbl, uint4
             if (SELF) { t1 = t2; t2 = tf; } else t1 = tf;
 #endif
         }
+    }
     }
 #ifdef DSM_CLOCK_PROBE
     if (gw == 0 && lane == 0) {  // shader clocks and 100 MHz ticks of this wave's sweep (build-time probe: the clock the kernel runs at)
@@ -822,6 +975,25 @@ void expand_batch_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters
     expand_sweep<P, ONESB, INC, OUTC, true>(S.ix, sbl, parked, &tile_ctr, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax, S.pplane);
 }
 
+// the same, every sample's own nodes packed into full tiles (compact records only: LfConfig::dense)
+template <typename P, bool ONESB, bool OUTC>
+__global__ __launch_bounds__((LfShape<P, true, true>::WPB * 64)) __attribute__((amdgpu_waves_per_eu((LfShape<P, true, true>::WAVES_PER_SIMD))))
+void expand_dense_kernel(ExpandBatch b, ExpandArgs a, u64* __restrict__ counters, unsigned long long* __restrict__ childmax) {
+    __shared__ u64 sbl[ONESB ? 1 : SB_LDS_MAX * 4];
+    __shared__ uint4 parked[LfShape<P, true, true>::WPB * WAVE_LDS_WORDS];
+    __shared__ u32 dense_lds[LfShape<P, true, true>::WPB * DENSE_LDS_WORDS];
+    __shared__ u32 tile_ctr;
+    const ExpandSample& S = b.s[blockIdx.y];
+    a.sb = S.sb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.cost[c] = S.cost[c];
+    a.access_pack = S.access_pack;
+    a.costsum_lo = S.costsum_lo;
+    a.costsum_hi = S.costsum_hi;
+    expand_sweep<P, ONESB, true, OUTC, true, true>(S.ix, sbl, parked, &tile_ctr, S.rp, (const P*)S.rec, (P*)S.out, S.splane, nullptr, (P*)S.valf, S.pl, a, counters, childmax,
+                                                   S.pplane, dense_lds);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -882,11 +1054,36 @@ void lf_step_launch_batch(const LfConfig& c, const LfGeometry& g, u32 grid_facto
     // workgroup is another start-up, and a workgroup's waves balance their tiles among themselves anyway); round 3's workgroups of four
     // waves wanted 8 (972 ms).
     const u32 ntile = (a.F + 63) >> 6;
+    u32 gx = (grid_factor ? grid_factor : 1u) * g.blocks / (u32)nb;
+    if (gx < 1) gx = 1;
+    if (c.dense && c.fmt_in) {
+        // items of union tiles: as large as leaves every wave of the sample's share of the card a few of them (a short last tile per item)
+        const u32 wpbd = (u32)LfShape<u32, true, true>::WPB;
+        ExpandArgs ad = a;
+        u32 item = DENSE_ITEM_MAX;
+        while (item > 4 && (u64)ntile < (u64)item * gx * wpbd * 4) item >>= 1;
+        ad.item_tiles = item;
+        const u32 nitem = (ntile + item - 1) / item;
+        u32 needd = (nitem + wpbd - 1) / wpbd;
+        if (needd < 1) needd = 1;
+        const dim3 gridd(needd < gx ? needd : gx, (u32)nb);
+        const dim3 blk(wpbd * 64);
+        if (c.wide_pos) {
+            if (c.one_sb) { if (c.fmt_out) hipLaunchKernelGGL((expand_dense_kernel<u64, true, true>), gridd, blk, 0, st, b, ad, counters, childmax);
+                            else hipLaunchKernelGGL((expand_dense_kernel<u64, true, false>), gridd, blk, 0, st, b, ad, counters, childmax); }
+            else          { if (c.fmt_out) hipLaunchKernelGGL((expand_dense_kernel<u64, false, true>), gridd, blk, 0, st, b, ad, counters, childmax);
+                            else hipLaunchKernelGGL((expand_dense_kernel<u64, false, false>), gridd, blk, 0, st, b, ad, counters, childmax); }
+        } else {
+            if (c.one_sb) { if (c.fmt_out) hipLaunchKernelGGL((expand_dense_kernel<u32, true, true>), gridd, blk, 0, st, b, ad, counters, childmax);
+                            else hipLaunchKernelGGL((expand_dense_kernel<u32, true, false>), gridd, blk, 0, st, b, ad, counters, childmax); }
+            else          { if (c.fmt_out) hipLaunchKernelGGL((expand_dense_kernel<u32, false, true>), gridd, blk, 0, st, b, ad, counters, childmax);
+                            else hipLaunchKernelGGL((expand_dense_kernel<u32, false, false>), gridd, blk, 0, st, b, ad, counters, childmax); }
+        }
+        return;
+    }
     const u32 wpb = c.fmt_in ? g.waves_per_block : (u32)(c.wide_pos ? LfShape<u64, false>::WPB : LfShape<u32, false>::WPB);
     u32 need = (ntile + wpb - 1) / wpb;
     if (need < 1) need = 1;
-    u32 gx = (grid_factor ? grid_factor : 1u) * g.blocks / (u32)nb;
-    if (gx < 1) gx = 1;
     const dim3 grid(need < gx ? need : gx, (u32)nb);
     if (c.wide_pos) DSM_LF_DISPATCH(launchb, u64, grid, st, b, a, counters, childmax);
     else DSM_LF_DISPATCH(launchb, u32, grid, st, b, a, counters, childmax);

@@ -88,6 +88,7 @@ struct ExpandArgs {
     // (formats are launch-time choices) or the level does not fit -- the host then sees the same words and launches again.
     const u32* dyn;    // null: F, nbp and the formats above are final
     u32 dyn_expect, dyn_mask, fcap;
+    u32 item_tiles;    // dense sweeps (one sample among several, expand.hip): union tiles a wave takes at a time, a power of two <= 32
     u32 probe_slot;    // DSM_CLOCK_PROBE builds: counter shard that collects this launch's wave times
 };
 
@@ -118,6 +119,7 @@ struct LfConfig {
     bool one_sb;     // every index of the launch has one superblock
     bool fmt_in;     // this level's records are compact
     bool fmt_out;    // the children's records are compact
+    bool dense;      // lf_step_launch_batch: pack every sample's own nodes into full tiles (compact levels that are wide enough)
 };
 // What a launch looks like on this device: the workgroups that are resident at once and how many tiles of 64 nodes one of them takes
 // per round (its waves).  The engine sizes small launches with it.

@@ -283,6 +283,41 @@ def test_thirty_samples_exact_pair_order(golden, pydsm_mod):
         ix.close()
 
 
+def test_dense_sweeps_on_every_compact_level(golden, pydsm_mod, monkeypatch):
+    """Several samples: on wide levels a sample's own nodes are packed into full tiles (expand.hip, DENSE) -- handles of the children from
+    runs of lanes of one union tile plus what the previous dense tile held of it, planes put together in LDS, column entries of the
+    absent nodes cleared by the producer.  DSM_DENSE_MIN=0 sends every compact level of the small golden sets through it (items of
+    four union tiles): tuples against the reference server's stdout and the oracle, all six counters against the oracle, with 32- and
+    64-bit positions, d = 3, 5 and 30, also with budgets small enough to split prefixes."""
+    monkeypatch.setenv("DSM_DENSE_MIN", "0")
+    for setname, fmin in (("toy3", 2), ("five", 10)):
+        m = golden.manifest["sets"][setname]
+        idx = [pydsm_mod.Index(golden.fmi(setname, n)) for n in m["names"]]
+        oidx = [orc.Index(golden.fmi(setname, n)) for n in m["names"]]
+        for wide in (0, 1):
+            for p in ["", "A", "C", "G", "T", "GT"]:
+                kw = dict(fmin=fmin, emax=2.0, pmin=1 if p == "" else 2)
+                got, st = pydsm_mod.mine(idx, p, wide=wide, **kw)
+                want, ost = orc.mine(oidx, m["names"], [p], **kw)
+                assert got == want, (setname, wide, p)
+                assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (setname, wide, p)
+                if len(p) == 1:
+                    assert got == golden.server_out(setname, "default", p)
+        got, st = pydsm_mod.mine(idx, "A", fmin=fmin, emax=2.0, arena_bytes=3 << 20)   # forced prefix splits
+        want, _ = orc.mine(oidx, m["names"], ["A"], fmin=fmin, emax=2.0)
+        assert got == want and (setname == "toy3" or st.splits > 0)
+        for ix in idx + oidx:
+            ix.close()
+    m = golden.manifest["sets"]["many30"]
+    idx = [pydsm_mod.Index(golden.fmi("many30", n)) for n in m["names"]]
+    for cfg, args in m["server_cfgs"].items():
+        for p in m["prefixes"]:
+            got, st = pydsm_mod.mine(idx, p, fmin=m["fmin"], maxdepth=m["maxdepth"], **server_args_to_kw(args))
+            assert got == golden.server_out("many30", cfg, p), (cfg, p)
+    for ix in idx:
+        ix.close()
+
+
 def _downgrade_fmi(raw, ver):
     """Rewrite a v17 .fmi as v16 / v15 / v14 (FMIndex.cpp:267-290, HuffWT.h:21-37): v<16 stores code counts as u32, v14 stores C[] as u32."""
     import struct
