@@ -27,3 +27,17 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCL
 done
 python3 "$R/tools/profiling/make_traffic.py" traffic "$O/r04_pmc.txt" "$O/r04_bench.json" "$O/r04_trace_summary.json" > "$O/r04_traffic.json"
 cat "$O/r04_traffic.json"
+# ---- eight samples on the one card (dense LF-step sweeps): kernel stats of one record's two passes, counters of the dense kernel ----
+cd "$R" && python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-seconds 1 --extras d8 > "$O/r04_d8_bench.json" 2> /dev/null   # (builds the indexes; the line itself is kept)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/r04_prof_d8" -- python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-seconds 1 --extras d8 > "$O/r04_prof_d8.log" 2>&1
+cp "$(find "$O/r04_prof_d8" -name "*kernel_stats.csv" | head -1)" "$O/r04_kernel_stats_8samples.csv"
+rm -rf "$O/r04_prof_d8"
+rm -f "$O/r04_pmc_d8.txt"
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+  n=$(echo "$c" | tr ' ' '_' | cut -c1-24)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/r04_pmc8_$n" -- python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-seconds 1 --extras d8 > "$O/r04_pmc8_$n.log" 2>&1 || echo "fail $n"
+  python3 "$R/tools/profiling/pmc_agg.py" "$O/r04_pmc8_$n" >> "$O/r04_pmc_d8.txt"
+  rm -rf "$O/r04_pmc8_$n"
+  echo "pmc d8 $n done"
+done
