@@ -342,6 +342,10 @@ struct AdvanceOut {
     FilterArgs fa;
     u64* candbits;       // per wave of 64 nodes: which of them are candidates
     u64* wsum;           // per wave: candidates | pairs << 32
+    // one sample, advance_single_kernel: the candidates' records {node, 0, frequency} are stored by the sweep itself -- their places come
+    // from the fifth row of the tile counts (candidates per tile, scanned along with the child counts)
+    uint4* crec;         // null: the candidate store is a kernel of its own (cand_store_kernel)
+    u32 crec_cap;        // records the block holds (a level with more is stored the old way)
 };
 
 // The few words the host reads after a level travel as ONE 16-byte store to pinned host memory: {sequence number, width of
@@ -359,6 +363,7 @@ struct PublishArgs {
     uint4* packet;        // pinned, 16-byte aligned
     u32 seq;
     uint4* bc_header;     // owner mode: the same packet at the head of the broadcast message (device), may be null
+    const u32* grand;     // (candidate counts scanned behind the child counts) grand total of that scan: candidates = *grand - *total, one pair each
 };
 __global__ void publish_kernel(PublishArgs a) {
     __shared__ u32 wide;  // bit 0: some child frequency of the level is 65535 or more, bit 1: 512 or more
@@ -369,7 +374,8 @@ __global__ void publish_kernel(PublishArgs a) {
         if (m >= PACK_FMAX) atomicOr(&wide, m >= 65535 ? 3u : 2u);
     }
     const u32 tot = threadIdx.x == 0 ? *a.total : 0u;
-    const u64 cand = threadIdx.x == 0 && a.cand ? *a.cand : 0ull;
+    u64 cand = threadIdx.x == 0 && a.cand ? *a.cand : 0ull;
+    if (threadIdx.x == 0 && a.grand) { const u64 c = (u64)(*a.grand - tot); cand = c | (c << 32); }
     __syncthreads();
     if (a.clear && threadIdx.x < 4) a.clear[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
@@ -635,8 +641,9 @@ __global__ __launch_bounds__(256) void advance_wave_kernel(Xchg x, AdvanceOut o)
 // rounds are scalar sums, no LDS and no barrier; the parents' path words of all four rounds are requested before the first is used.
 // (the line of a round, written by the LF-step kernel: {plane[4], candidate bits, candidates | pairs << 32, -, -}, ExpandArgs::symbol_phase)
 template <typename P>
-__global__ __launch_bounds__(256) void advance_single_kernel(u32 F, AdvanceOut o) {
+__global__ __launch_bounds__(256) void advance_single_kernel(Xchg x, AdvanceOut o) {
     const int lane = threadIdx.x & 63;
+    const u32 F = (u32)x.F;
     const u32 nw = (F + 63) >> 6;
     const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)(xcd_block() * 4 + (threadIdx.x >> 6)));
     if (tile >= o.nbp) return;
@@ -670,10 +677,23 @@ __global__ __launch_bounds__(256) void advance_single_kernel(u32 F, AdvanceOut o
     }
     const u32 r = o.plevel & (PW_CHUNK - 1);
     u32 kc = 0;   // lane 4q + c: index of the first child c of round q
+    u32 cbase = 0;  // (candidate store) record of the round's first candidate
+    if (o.crec) cbase = o.cnt4[(size_t)4 * o.nbp + tile] - o.cnt4[(size_t)4 * o.nbp];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32 w = tile * 4 + (u32)q, u = w * 64 + lane;
         const uint2 ppw = mypw[q];
+        if (o.crec && w < nw) {   // this round's candidates: node, frequency (metaserver.cpp:472-484 prints id:frequency; one sample: id 0)
+            const u64 cb = line[q * 8 + 4];
+            if (cb) {
+                const u32 k = cbase + bits_below_lane(cb);
+                if (((cb >> lane) & 1ull) && k < o.crec_cap) {
+                    const u64 f = (u64)x_freq<P>(x, 0, u);
+                    o.crec[k] = make_uint4(u, 0u, (u32)f, (u32)(f >> 32));
+                }
+            }
+            cbase += (u32)line[q * 8 + 5];
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const u64 m = up[q][c];
@@ -696,13 +716,21 @@ __global__ __launch_bounds__(256) void advance_single_kernel(u32 F, AdvanceOut o
 // LF-step kernel derives the handles of its own records (expand_tile, SELF).  Tile counts, one scan, links.
 // ---------------------------------------------------------------------------------------------
 // (kshift: log2 of the words a wave's entry takes in kplane -- 2, or 3 for the whole lines a single sample's LF-step kernel writes)
-__global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__ kplane, u32 nw, u32* __restrict__ cnt4, u32 nbp, u32 kshift) {
+// cand_row (kshift 3: the lines a single sample's LF-step kernel writes): a fifth row, the tile's candidates (word 5 of a line)
+__global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__ kplane, u32 nw, u32* __restrict__ cnt4, u32 nbp, u32 kshift, u32 cand_row = 0) {
     const u32 tile = blockIdx.x * 64 + (threadIdx.x >> 2), c = threadIdx.x & 3;  // one thread per (tile, symbol)
     if (tile >= nbp) return;
-    u32 s = 0;
+    u32 s = 0, nc = 0;
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) { const u32 w = tile * 4 + q; if (w < nw) s += (u32)__popcll(kplane[((size_t)w << kshift) + c]); }
+    for (u32 q = 0; q < 4; ++q) {
+        const u32 w = tile * 4 + q;
+        if (w < nw) {
+            s += (u32)__popcll(kplane[((size_t)w << kshift) + c]);
+            if (cand_row && c == 0) nc += (u32)kplane[((size_t)w << 3) + 5];
+        }
+    }
     cnt4[(size_t)c * nbp + tile] = s;
+    if (cand_row && c == 0) cnt4[(size_t)4 * nbp + tile] = nc;
 }
 __global__ __launch_bounds__(256) void lite_slot_kernel(const u64* __restrict__ kplane, u32 F, const u32* __restrict__ cnt4, u32 nbp, u32 single_tile,
                                                         u32* __restrict__ slot, u32 cap) {
@@ -1099,22 +1127,24 @@ __global__ __launch_bounds__(256) void down_kernel(u32 F, const T* __restrict__ 
 
 // candidate k of a level gets its post-order rank among all candidates of the prefix; the tuple's sizes go to their place
 // in output order (the ranks of neighbouring candidates are far apart: the levels are in colex order, the output in trie order)
+// (crec: the records the advance sweep of a single sample stored -- node, 0, frequency -- instead of the four arrays: one pair each)
 __global__ void cand_rank_kernel(u32 ncand, const u32* __restrict__ cand_node, const u32* __restrict__ cand_poff, u32 npairs,
                                  const u32* __restrict__ start, const u32* __restrict__ sub, u32 level, u32* __restrict__ crank,
-                                 u32* __restrict__ plen, u32* __restrict__ npair) {
+                                 u32* __restrict__ plen, u32* __restrict__ npair, const uint4* __restrict__ crec) {
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncand) return;
-    u32 v = cand_node[k];
+    u32 v = crec ? crec[k].x : cand_node[k];
     u32 r = start[v] + sub[v] - 1;
     crank[k] = r;
     plen[r] = level;
-    npair[r] = (k + 1 < ncand ? cand_poff[k + 1] : npairs) - cand_poff[k];
+    npair[r] = crec ? 1u : (k + 1 < ncand ? cand_poff[k + 1] : npairs) - cand_poff[k];
 }
 
 struct LevelDev {
     const uint2* pw;    // path words of the level's nodes (see AdvanceOut)
     const u32* cand_node;
     const u32* cand_poff;
+    const uint4* crec;  // (one sample, stored by the advance sweep: {node, 0, frequency} per candidate instead of the arrays around it)
     const u32* crank;   // post-order rank of candidate k
     const u32* ids;
     const u64* freqs;
@@ -1179,16 +1209,18 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
     const u32 k = f - L.cbase;
     const u32 r = L.crank[k];
     if (r < rank_lo || r >= rank_hi) return;  // (a launch fills one chunk of consecutive output ranks)
-    const u32 b = L.cand_poff[k];
-    const u32 e = k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs;
+    const bool one = L.crec != nullptr;
+    const uint4 cr = one ? L.crec[k] : make_uint4(0u, 0u, 0u, 0u);
+    const u32 b = one ? k : L.cand_poff[k];
+    const u32 e = one ? k + 1 : (k + 1 < L.ncand ? L.cand_poff[k + 1] : L.npairs);
     u32 o = pair_off[r];
     const u32 o_first = o, p_first = path_off[r];
     u64 sumN = fv.d;
     double sl = 0;
     bool beyond = false;
     for (u32 q = b; q < e; ++q, ++o) {
-        const u64 fq = L.freqs[q];
-        ids[o] = L.ids[q]; freqs[o] = fq;
+        const u64 fq = one ? (((u64)cr.w << 32) | cr.z) : L.freqs[q];
+        ids[o] = one ? 0u : L.ids[q]; freqs[o] = fq;
         sumN += fq;
         if (fv.ent && !beyond) {
             if (fq < TERM_TAB) sl += fv.terms[fq]; else beyond = true;
@@ -1215,7 +1247,7 @@ __global__ __launch_bounds__(256) void tuple_fill_kernel(u32 nt, u32 nlev, const
             if (mh) atomicAdd(fv.counts + 1, (u32)__popcll(mh));
         }
     }
-    u32 v = L.cand_node[k];
+    u32 v = one ? cr.x : L.cand_node[k];
     char* dst = paths + p_first;
     u32 l = lvl;
     while (l > 0) {
@@ -1457,6 +1489,7 @@ struct LevelHost {
     u32 ncand = 0, npairs = 0;
     u32* cand_node = nullptr;
     u32* cand_poff = nullptr;
+    uint4* crec = nullptr;      // (one sample: the candidates as the advance sweep stored them, see AdvanceOut::crec)
     u32* ids = nullptr;
     u64* freqs = nullptr;
     u32* sub = nullptr;
@@ -2085,6 +2118,8 @@ class Engine {
     std::vector<void*> owned;
     size_t owned_bytes = 0;   // device bytes behind `owned` (page-rounded)
     Arena arena;
+    Arena carena;          // one sample: the candidate records the advance sweep stores (a block that is cut to size after the level)
+    bool fold_cands = true;   // DSM_FOLD_CANDS=0: cand_store_kernel on every level (A/B runs)
     Arena earena;          // multi-rank: emission-side allocations
     Arena* ea = nullptr;   // &earena, or &arena in single-process runs
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2270,7 +2305,7 @@ class Engine {
         DSM_HIP(hipMemcpy(d_tpos_tab, tpos.data(), (size_t)nlocal * sizeof(u32*), hipMemcpyHostToDevice));
         if (int rc = dalloc(d_splane_tab, (size_t)nlocal)) return rc;
         DSM_HIP(hipMemcpy(d_splane_tab, splane.data(), (size_t)nlocal * sizeof(u64*), hipMemcpyHostToDevice));
-        if (int rc = dalloc(cnt4, 4 * ntile + 8)) return rc;
+        if (int rc = dalloc(cnt4, 5 * ntile + 8)) return rc;   // (fifth row: candidates per tile, one sample)
         if (stream_mode)
             for (int k = 0; k < 2; ++k) if (int rc = dalloc(sa[k], (size_t)Fcap + 64)) return rc;
         if (owner_mode) {
@@ -2278,12 +2313,12 @@ class Engine {
             for (int k = 0; k < 2; ++k) if (int rc = dalloc(lite_slot[k], (size_t)Fcap + 64)) return rc;
         }
         if (d == 1 && !trie_mode) {
-            if (int rc = dalloc(cntraw, 4 * ntile + 8)) return rc;
-            DSM_HIP(hipMemset(cntraw, 0, (4 * ntile + 8) * sizeof(u32)));
+            if (int rc = dalloc(cntraw, 5 * ntile + 8)) return rc;
+            DSM_HIP(hipMemset(cntraw, 0, (5 * ntile + 8) * sizeof(u32)));
         }
         if (int rc = lf_step_geometry(sizeof(P) == 8, device, &lfgeo)) return rc;  // (all waves of an LF-step launch are resident)
         if (d > 1 || trie_mode) { if (int rc = dalloc(sinfo, (size_t)slots)) return rc; }
-        if (int rc = dalloc(scan_tmp, scan_tmp_elems(4 * ntile) + 8)) return rc;
+        if (int rc = dalloc(scan_tmp, scan_tmp_elems(5 * ntile) + 8)) return rc;
         for (int k = 0; k < 2; ++k) {
             if (int rc = dalloc(nT[k], Fcap)) return rc;
             if (int rc = dalloc(order[k], Fcap)) return rc;
@@ -2334,6 +2369,14 @@ class Engine {
             earena.base = arena.base + arena.cap;
             earena.cap = arena_b - arena.cap;
             ea = &earena;
+        }
+        if (const char* e = getenv("DSM_FOLD_CANDS")) fold_cands = atoi(e) != 0;
+        if (d == 1 && !multi && !stream_mode && !trie_mode && fold_cands) {
+            // one sample mined: a sixteenth of the arena for the candidate records (16 B each; at the benchmark size one node in forty is a
+            // candidate and a level retains ≈12 B per node: the share is generous, and a level that does not fit is stored the old way)
+            carena.cap = (arena.cap / 16) & ~(size_t)255;
+            arena.cap -= carena.cap;
+            carena.base = arena.base + arena.cap;
         }
         // (timing events without the system-scope fence a default event carries: the records bracket every LF-step launch, and a
         // fence there would write the L2 back twice per level)
@@ -2427,6 +2470,7 @@ class Engine {
             if (!idx[s_]->dev.blk) return fail(DSM_E_INVAL, "an index of this miner is offloaded: dsm_index_reload first");
         arena.off = 0;
         earena.off = 0;
+        carena.off = 0;
         bool emitting = emit;       // cleared when this rank's emission side runs out of memory in a multi-rank run
         bool emit_failed = false;
         std::vector<LevelHost> L;
@@ -2783,11 +2827,22 @@ class Engine {
                 ao.kplane = splane[0]; ao.kplane_w = me.kplane; ao.single = 1;
                 ao.kshift = 3;
             }
+            static const bool lean_sweep = !(getenv("DSM_LEAN_ADVANCE") && atoi(getenv("DSM_LEAN_ADVANCE")) == 0);
+            const bool lean = lean_sweep && !merged && nbp > 1 && keep_pw && !keep_slot && !stream_mode;   // advance_single_kernel takes the level
+            // One sample: the level's candidates are stored by the sweep itself.  Their number is known only after it: the records go
+            // to a block of their own arena, taken as large as the level could need and cut to size after the synchronisation.
+            bool fold = false;
+            u32 crec_cap = 0;
+            if (lean && filtered && carena.cap) {
+                const size_t room = (carena.cap - carena.off) / sizeof(uint4);
+                crec_cap = (u32)(room < (size_t)F ? room : (size_t)F);
+                fold = crec_cap > 0;
+            }
             if (nbp > 1) {
                 // one sample: the tile counts from the planes its LF-step kernel wrote (that kernel added them up with four atomics per
-                // tile of 64 nodes before: 470 K memory-side atomics per launch of the wide levels)
-                if (!merged) hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, splane[0], (F + 63) >> 6, cntraw, nbp, 3u);
-                exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)4 * nbp, scan_tmp, d_totals, st);
+                // tile of 64 nodes before: 470 K memory-side atomics per launch of the wide levels); with them the candidates per tile
+                if (!merged) hipLaunchKernelGGL(lite_count_kernel, dim3((nbp + 63) / 64), dim3(256), 0, st, splane[0], (F + 63) >> 6, cntraw, nbp, 3u, fold ? 1u : 0u);
+                exclusive_scan<u32, u32>(merged ? cnt4 : cntraw, cnt4, (size_t)(fold ? 5 : 4) * nbp, scan_tmp, d_totals, st);
             }
             // ---- the output predicates for the nodes of THIS level (their children are known now) ride in the wave sweep; the scan of
             // the candidate counts is queued ahead of the wait ----
@@ -2797,13 +2852,12 @@ class Engine {
                 if (ao.single) ao.cand_copy = 1;  // (the level's LF-step kernel decided: the sweep only moves the words into place)
                 else ao.filter_on = 1;
             }
-            static const bool lean_sweep = !(getenv("DSM_LEAN_ADVANCE") && atoi(getenv("DSM_LEAN_ADVANCE")) == 0);
+            if (fold) { ao.crec = reinterpret_cast<uint4*>(carena.base + carena.off); ao.crec_cap = crec_cap; }
             if (nbp == 1) hipLaunchKernelGGL((advance_down_kernel<P>), dim3(1), dim3(256), 0, st, x, ao);
-            else if (lean_sweep && ao.single && ao.kshift == 3 && ao.pw && !ao.slot && !ao.sa && !ao.filter_on && ao.kplane_w)
-                hipLaunchKernelGGL((advance_single_kernel<P>), dim3((nbp + 3) / 4), dim3(256), 0, st, F, ao);
+            else if (lean) hipLaunchKernelGGL((advance_single_kernel<P>), dim3((nbp + 3) / 4), dim3(256), 0, st, x, ao);
             else hipLaunchKernelGGL((advance_wave_kernel<P>), dim3(nbp), dim3(256), 0, st, x, ao);
             if (filtered) {
-                if (int erc = emit_filter(me, F, depth, x, cur, order_mode, !fused_filter)) return erc;
+                if (int erc = emit_filter(me, F, depth, x, cur, order_mode, !fused_filter, fold)) return erc;
             }
             {
                 PublishArgs pa;
@@ -2811,6 +2865,11 @@ class Engine {
                 pa.total = nbp == 1 ? d_pub_tot : d_totals;  // new level's width: from the single tile, or the scan's total
                 pa.cmax_base = x.base; pa.cmax_bpr = x.bpr; pa.cmax_world = (u32)world;
                 if (filtered) pa.cand = d_totals64;
+                if (fold) {  // the scan ran over the child counts and, behind them, the candidate counts: the width is what it had reached there
+                    pa.total = cnt4 + (size_t)4 * nbp;
+                    pa.grand = d_totals;
+                    pa.cand = nullptr;
+                }
                 pa.clear = reinterpret_cast<u32*>(multi ? xsend : xrecv[xcur ^ 1]);  // where the next level's expand reports its child maximum
                 pa.packet = reinterpret_cast<uint4*>(h_totals + 304); pa.seq = ++pub_seq;
                 pa.next = spec_mode ? d_dyn : nullptr;
@@ -2923,7 +2982,7 @@ class Engine {
                 }
             }
             if (filtered) {  // the candidates of this level: totals arrived with the synchronisation above
-                int erc = emit_store(me, F, depth, x, cur, order_mode);
+                int erc = emit_store(me, F, depth, x, cur, order_mode, fold ? crec_cap : 0u);
                 if (erc == DSM_E_CAPACITY && multi) { emit_failed = true; emitting = false; }
                 else if (erc) return erc;
             }
@@ -3037,19 +3096,28 @@ class Engine {
         EARENA_GET(me.cand_bits, u64, ((size_t)F + 63) / 64);
         return 0;
     }
-    int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode, bool run_kernel) {
+    int emit_filter(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode, bool run_kernel, bool stored = false) {
         const FilterArgs fa = filter_args(F, depth, order_mode);
         if (run_kernel)  // (single-tile levels; larger ones evaluate the predicates inside the advance sweep)
             hipLaunchKernelGGL((filter_kernel<P>), grid_npt(F), dim3(256), 0, st, fa, xp, nT[cur], me.kids(), samechild, me.cand_bits, cand_wsum);
-        exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
+        // (stored: the sweep stored the candidates itself, their places from the scan of the tile counts)
+        if (!stored) exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
         return 0;
     }
-    int emit_store(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode) {  // after the level's synchronisation
+    // stored_cap > 0: the advance sweep stored the level's candidates as records at the top of the candidate arena, up to that many
+    int emit_store(LevelHost& me, u32 F, u32 depth, const Xchg& xp, int cur, u32 order_mode, u32 stored_cap = 0) {  // after the level's synchronisation
         const FilterArgs fa = filter_args(F, depth, order_mode);
         u64 tot = 0;
         memcpy(&tot, h_totals + 300, sizeof tot);
         me.ncand = (u32)(tot & 0xFFFFFFFFu);
         me.npairs = (u32)(tot >> 32);
+        if (stored_cap && me.ncand <= stored_cap) {   // the block is cut to the records the level has
+            if (me.ncand) me.crec = carena.get<uint4>(me.ncand);
+            stats.candidates += me.ncand;
+            return 0;
+        }
+        if (stored_cap)   // more candidates than the block could take (its records beyond were not written): the old way, from the words
+            exclusive_scan<u64, u64>(cand_wsum, cand_wscan, ((size_t)F + 63) / 64, scan_tmp64, d_totals64, st);
         if (me.ncand) {
             u32 nc = me.ncand;
             me.ncand = 0;  // stays 0 if the store does not fit: the level then has no usable candidates
@@ -3101,13 +3169,13 @@ class Engine {
             hipLaunchKernelGGL((down_kernel<u32>), grid_npt(L[l].n), dim3(256), 0, st, L[l].n, s_cur, 0u, L[l].kids(), L[l + 1].sub, s_next);
             if (L[l + 1].ncand)
                 hipLaunchKernelGGL(cand_rank_kernel, grid_for(L[l + 1].ncand), dim3(256), 0, st, L[l + 1].ncand, L[l + 1].cand_node, L[l + 1].cand_poff,
-                                   L[l + 1].npairs, s_next, L[l + 1].sub, l + 1, crank[l + 1], plen, npair);
+                                   L[l + 1].npairs, s_next, L[l + 1].sub, l + 1, crank[l + 1], plen, npair, L[l + 1].crec);
         }
         // tuple sizes -> offsets
         std::vector<LevelDev> lv(nlev);
         u32 cb = 0;
         for (u32 l = 0; l < nlev; ++l) {
-            lv[l].pw = L[l].pw; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff; lv[l].crank = crank[l];
+            lv[l].pw = L[l].pw; lv[l].cand_node = L[l].cand_node; lv[l].cand_poff = L[l].cand_poff; lv[l].crec = L[l].crec; lv[l].crank = crank[l];
             lv[l].ids = L[l].ids; lv[l].freqs = L[l].freqs; lv[l].ncand = l ? L[l].ncand : 0; lv[l].npairs = L[l].npairs;
             lv[l].cbase = cb;
             cb += lv[l].ncand;
