@@ -155,7 +155,9 @@ typedef struct dsm_tuple_batch {
     const uint64_t* freqs;
 } dsm_tuple_batch;
 
-/* Receives tuples in the reference's output order (post-order, metaserver.cpp:467-485). */
+/* Receives tuples in the reference's output order (post-order, metaserver.cpp:467-485): batches of consecutive tuples, offsets starting
+ * at 0, as many calls per prefix as the emitter finds convenient (a prefix leaves in chunks of about a million tuples or more; a chunk
+ * in which a few tuples failed the entropy test on the host leaves as the runs between them).  The arrays are valid during the call. */
 typedef int (*dsm_tuple_sink)(void* ctx, const dsm_tuple_batch* batch);
 
 /* One exchange per frontier level (per frontier node and local sample: the node's frequency in 2 bytes -- 4 or 8 on the

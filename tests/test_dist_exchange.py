@@ -100,10 +100,12 @@ def _gpu_worker(rank, world, port, q, fmis, prefixes, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("setname,world,cfg", [("toy3", 3, "default"), ("five", 5, "default"), ("toy3", 3, "pmax2"),
-                                                ("many30", 5, "p3")])   # 5 ranks x 6 samples: several samples per rank, d = 30
-def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cfg):
+@pytest.mark.parametrize("setname,world,cfg,dense", [("toy3", 3, "default", 0), ("five", 5, "default", 1), ("toy3", 3, "pmax2", 1),
+                                                      ("many30", 5, "p3", 0), ("many30", 5, "p3", 1)])   # 5 ranks x 6 samples: several samples per rank, d = 30
+def test_one_sample_per_rank_matches_reference_server(golden, setname, world, cfg, dense, monkeypatch):
     import orc
+    if dense:   # every compact level through the dense LF-step sweep (the workers inherit the environment)
+        monkeypatch.setenv("DSM_DENSE_MIN", "0")
     from goldenlib import server_args_to_kw
     m = golden.manifest["sets"][setname]
     names = m["names"]
@@ -203,7 +205,9 @@ def _owner_worker(rank, world, port, q, fmis, prefixes, kw, arena):
 @pytest.mark.gpu
 @pytest.mark.parametrize("setname,world,cfg,arena", [("toy3", 3, "default", 0), ("toy3", 3, "default", 5 << 20), ("five", 5, "default", 0),
                                                       ("many30", 5, "p3", 0)])   # (fewer prefixes than ranks: some lanes stay idle)
-def test_owner_mode_one_server_per_prefix(golden, setname, world, cfg, arena):
+def test_owner_mode_one_server_per_prefix(golden, setname, world, cfg, arena, monkeypatch):
+    if setname != "toy3" or arena:   # (these cases: the dense LF-step sweep on every compact level, owner and clients alike)
+        monkeypatch.setenv("DSM_DENSE_MIN", "0")
     """The reference's partition (one metaserver per prefix, wrapper-SLURM/example-server.sh:27-41; one client connection per
     prefix, metaenumerate.cpp:268-309) between ranks: prefix k is merged by rank k % world alone, the others send it their
     columns and get the union's child masks back.  Tuples of every prefix equal the reference server's stdout; a client receives
