@@ -678,22 +678,27 @@ __global__ __launch_bounds__(256) void advance_single_kernel(Xchg x, AdvanceOut 
     const u32 r = o.plevel & (PW_CHUNK - 1);
     u32 kc = 0;   // lane 4q + c: index of the first child c of round q
     u32 cbase = 0;  // (candidate store) record of the round's first candidate
-    if (o.crec) cbase = o.cnt4[(size_t)4 * o.nbp + tile] - o.cnt4[(size_t)4 * o.nbp];
+    u64 cbq[4] = {0, 0, 0, 0};   // candidate bits of the four rounds, their counts, this lane's frequencies where it is one
+    u32 ncq[4] = {0, 0, 0, 0};
+    u64 fq[4] = {0, 0, 0, 0};
+    if (o.crec) {
+        cbase = o.cnt4[(size_t)4 * o.nbp + tile] - o.cnt4[(size_t)4 * o.nbp];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (tile * 4 + (u32)q < nw) { cbq[q] = line[q * 8 + 4]; ncq[q] = (u32)line[q * 8 + 5]; }
+            const u32 u = (tile * 4 + (u32)q) * 64 + lane;
+            if ((cbq[q] >> lane) & 1ull) fq[q] = (u64)x_freq<P>(x, 0, u);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32 w = tile * 4 + (u32)q, u = w * 64 + lane;
         const uint2 ppw = mypw[q];
-        if (o.crec && w < nw) {   // this round's candidates: node, frequency (metaserver.cpp:472-484 prints id:frequency; one sample: id 0)
-            const u64 cb = line[q * 8 + 4];
-            if (cb) {
-                const u32 k = cbase + bits_below_lane(cb);
-                if (((cb >> lane) & 1ull) && k < o.crec_cap) {
-                    const u64 f = (u64)x_freq<P>(x, 0, u);
-                    o.crec[k] = make_uint4(u, 0u, (u32)f, (u32)(f >> 32));
-                }
-            }
-            cbase += (u32)line[q * 8 + 5];
+        if (o.crec && cbq[q]) {   // this round's candidates: node, frequency (metaserver.cpp:472-484 prints id:frequency; one sample: id 0)
+            const u32 k = cbase + bits_below_lane(cbq[q]);
+            if (((cbq[q] >> lane) & 1ull) && k < o.crec_cap) o.crec[k] = make_uint4(u, 0u, (u32)fq[q], (u32)(fq[q] >> 32));
         }
+        cbase += ncq[q];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const u64 m = up[q][c];
@@ -721,16 +726,18 @@ __global__ __launch_bounds__(256) void lite_count_kernel(const u64* __restrict__
     const u32 tile = blockIdx.x * 64 + (threadIdx.x >> 2), c = threadIdx.x & 3;  // one thread per (tile, symbol)
     if (tile >= nbp) return;
     u32 s = 0, nc = 0;
+    if (cand_row && tile * 4 + c < nw) nc = (u32)kplane[((size_t)(tile * 4 + c) << 3) + 5];   // thread c: the candidates of the tile's wave c
 #pragma unroll
     for (u32 q = 0; q < 4; ++q) {
         const u32 w = tile * 4 + q;
-        if (w < nw) {
-            s += (u32)__popcll(kplane[((size_t)w << kshift) + c]);
-            if (cand_row && c == 0) nc += (u32)kplane[((size_t)w << 3) + 5];
-        }
+        if (w < nw) s += (u32)__popcll(kplane[((size_t)w << kshift) + c]);
     }
     cnt4[(size_t)c * nbp + tile] = s;
-    if (cand_row && c == 0) cnt4[(size_t)4 * nbp + tile] = nc;
+    if (cand_row) {   // (the four threads of a tile are neighbouring lanes)
+        nc += __shfl_xor(nc, 1, 64);
+        nc += __shfl_xor(nc, 2, 64);
+        if (c == 0) cnt4[(size_t)4 * nbp + tile] = nc;
+    }
 }
 __global__ __launch_bounds__(256) void lite_slot_kernel(const u64* __restrict__ kplane, u32 F, const u32* __restrict__ cnt4, u32 nbp, u32 single_tile,
                                                         u32* __restrict__ slot, u32 cap) {
