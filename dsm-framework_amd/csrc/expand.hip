@@ -187,7 +187,7 @@ template <typename P>
 __device__ __forceinline__ void decode_head(const RecHead<P, false>& h, NodeIn<P>& n) {
     n.sp = h.sp; n.ep = h.ep; n.e0min = h.e0min; n.e0max = h.e0max; n.e1min = h.e1min; n.e1max = h.e1max;
     n.e2min = h.e2min; n.e2max = h.e2max; n.e3min = h.e3min; n.e3max = h.e3max;
-    n.emask = h.flags & 15u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
+    n.emask = h.flags & 31u; n.live = (h.flags & 0x100u) != 0; n.r = h.r;
 }
 __device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<u32>& n) {
     const uint4 v = h.w[0];
@@ -197,7 +197,7 @@ __device__ __forceinline__ void decode_head(const RecHead<u32, true>& h, NodeIn<
     n.ep = n.live ? sp + (v.y & 0xFFFFu) : 0u;
     n.e0min = sp + (v.y >> 16); n.e0max = sp + (v.z & 0xFFFFu);
     n.e1min = sp + (v.z >> 16); n.e1max = sp + (v.w & 0xFFFFu);
-    n.emask = n.live ? (v.w >> 16) & 15u : 0u;
+    n.emask = n.live ? (v.w >> 16) & 31u : 0u;
 }
 __device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<u64>& n) {
     const uint4 v = h.w[0], x = h.w[1];
@@ -209,7 +209,7 @@ __device__ __forceinline__ void decode_head(const RecHead<u64, true>& h, NodeIn<
     n.e1min = sp + (v.w >> 16); n.e1max = sp + (x.x & 0xFFFFu);
     n.e2min = sp + (x.y & 0xFFFFu); n.e2max = sp + (x.y >> 16);   // (the 32-byte record holds all four slots)
     n.e3min = sp + (x.z & 0xFFFFu); n.e3max = sp + (x.z >> 16);
-    n.emask = n.live ? (x.x >> 16) & 15u : 0u;
+    n.emask = n.live ? (x.x >> 16) & 31u : 0u;
 }
 // A finished child: interval [nsp, nep], kept intervals 0 and 1 as absolute positions.  Slots 2, 3: written to the wide fields already,
 // except for the compact record of 64-bit positions, which takes them as packed 16-bit offsets (o2, o3: min | max << 16).
@@ -336,7 +336,10 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
     decode_head(hc, nd);
     const bool live = nd.live;
     const P sp = nd.sp, ep = nd.ep;
-    const u32 emask = nd.emask;
+    // (bit 4 of a record's mask: the node's parent had one occurrence, i.e. the reference reached it inside followOneBranch, which reads
+    // the node's BWT symbol even when the node lies at maxdepth: EnumerateQuery.cpp:105-149 against :151-153)
+    const u32 emask = nd.emask & 15u;
+    const bool by_branch = (nd.emask >> 4) & 1u;
     const u32 ne = __popc(emask);
     u32 keepw = ~0u;  // the word of the keep table that holds this node's frequency (requested here, used at the candidate ballot)
     const P freq1 = ep - sp + 1;   // (positions stay of type P: no 64-bit arithmetic on a 32-bit index)
@@ -498,7 +501,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             if (single) {
                 const bool go = a.allowed && ((nonempty >> lcode) & 1u) && lcode < 4;
                 n_lf = go ? 2 * ne + 2 : 0u;
-                n_rank = (a.allowed ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * cost_of(cost_pack, lcode & 3u) : 0u);
+                n_rank = ((a.allowed || by_branch) ? (a.access_pack >> (4 * lcode)) & 15u : 0u) + (go ? (2 * ne + 2) * cost_of(cost_pack, lcode & 3u) : 0u);
             }
             if (!live) { n_lf = 0; n_rank = 0; }
             acc.lf += (u32)lf_wave_sum_u64(n_lf);
@@ -565,6 +568,8 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
             splane[(size_t)t * 8 + lane] = word;
         }
     }
+    // (a node with one occurrence follows one branch: its child's record says so, see by_branch)
+    const u32 branch_bit = ((a.symbol_phase & 1u) && a.fmin <= 1u && sp == ep && live) ? 16u : 0u;
     // ---- child records.  A lane's work is the list of its (child, left-extension interval) pairs, child-major: most lanes have
     // one pair, one in ten has two, so a wave runs about two rounds instead of (most children) x (most intervals).  Per pair: LF
     // with the child's base at both ends of the parent's interval (EnumerateQuery.cpp:44-55) -- an end that coincides with sp or
@@ -637,11 +642,11 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
         for (int c = 0; c < 4; ++c) {
             if ((present >> c) & 1u) {
                 const u32 cnc = (cn4 >> (3 * c)) & 7u, cmc = (cm4 >> (4 * c)) & 15u;
-                if (OUTC) store_child<P, true>(out, cap, qa[c], Rsp[c], Rep[c] - 1, kl0[c], kh0[c], kl1[c], kh1[c], cnc, cmc, ko2[c], ko3[c]);
+                if (OUTC) store_child<P, true>(out, cap, qa[c], Rsp[c], Rep[c] - 1, kl0[c], kh0[c], kl1[c], kh1[c], cnc, cmc | branch_bit, ko2[c], ko3[c]);
                 else {
                     out[qa[c]] = Rsp[c];
                     out[cap + qa[c]] = Rep[c] - 1;
-                    reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[qa[c]] = (u8)cmc;
+                    reinterpret_cast<u8*>(out + (size_t)REC_FIELDS * cap)[qa[c]] = (u8)(cmc | branch_bit);
                 }
                 if (!OUTC) acc.rb_lane += (cnc < 2 ? cnc : 2u) * 2u * (u32)sizeof(P);
                 if (cnc > 2 && !slots_inline<P>(OUTC)) acc.rb_lane += (cnc - 2) * 2u * (u32)sizeof(P);
@@ -708,7 +713,7 @@ __device__ __forceinline__ void expand_tile(const DevIndex& ix, const u64* sbl, 
                 cm |= 1u << kk;
             }
             if (act && e == ne1 - 1) {
-                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm, ko2, ko3);
+                store_child<P, OUTC>(out, cap, q, nsp, nep1 - 1, kl0, kh0, kl1, kh1, cn, cm | branch_bit, ko2, ko3);
                 // (bytes of the child's record beyond the compact word / the fixed fields: rare or wide levels only)
                 if (!OUTC) acc.rb_lane += (cn < 2 ? cn : 2u) * 2u * (u32)sizeof(P);
                 if (cn > 2 && !slots_inline<P>(OUTC)) acc.rb_lane += (cn - 2) * 2u * (u32)sizeof(P);

@@ -318,6 +318,43 @@ def test_dense_sweeps_on_every_compact_level(golden, pydsm_mod, monkeypatch):
         ix.close()
 
 
+def test_dense_sweep_of_a_thin_sample(pydsm_mod, tmp_path, monkeypatch):
+    """Dense sweeps when a sample holds a few dozen nodes among tens of thousands of the union level (40 reads beside 30 000: its dense
+    tiles span hundreds of union tiles, most items hold none of its nodes), and a third sample shares nothing with the others.
+    Tuples and counters against the oracle, both position widths."""
+    from pydsm import builder
+    import torch
+    monkeypatch.setenv("DSM_DENSE_MIN", "0")
+    rng = np.random.default_rng(2024)
+    genome = rng.integers(0, 4, 60000)
+    other = rng.integers(0, 4, 3000)
+
+    def reads(g, k, ln=60):
+        st = rng.integers(0, len(g) - ln, k)
+        return np.stack([g[a:a + ln] for a in st]).astype(np.uint8)
+    sets = [reads(genome, 30000), reads(genome, 40), reads(other, 400)]
+    paths = []
+    for k, codes in enumerate(sets):
+        p = tmp_path / ("thin%d.fasta.fmi" % k)
+        builder.build_from_codes(torch.from_numpy(codes), str(p))
+        paths.append(str(p))
+    idx = [pydsm_mod.Index(p) for p in paths]
+    oidx = [orc.Index(p) for p in paths]
+    names = [ix.name for ix in idx]
+    for wide in (0, 1):
+        for p, kw in (("", dict(fmin=1, maxdepth=14, pmin=1, emax=9.0)), ("G", dict(fmin=2, pmin=1, emax=9.0)), ("T", dict(fmin=1, maxdepth=20, pmin=1, pmax=2, emax=9.0))):
+            # (pmin 1 throughout: the reference server loses its place in the streams on single-reader nodes above depth 7 otherwise.
+            # fmin 1 with a depth cut: a node of one occurrence AT the cut costs the reference one getL when it was reached inside
+            # followOneBranch and nothing when nextSymbol returned at once -- the records carry that bit, EnumerateQuery.cpp:105-153)
+            got, st = pydsm_mod.mine(idx, p, wide=wide, **kw)
+            want, ost = orc.mine(oidx, names, [p], threads=4, **kw)
+            assert got == want, (wide, p)
+            assert (st.reported, st.lf_steps, st.rank_ops, st.union_nodes, st.tuples, st.pairs) == ost, (wide, p)
+    assert st.max_frontier > 10000
+    for ix in idx + oidx:
+        ix.close()
+
+
 def _downgrade_fmi(raw, ver):
     """Rewrite a v17 .fmi as v16 / v15 / v14 (FMIndex.cpp:267-290, HuffWT.h:21-37): v<16 stores code counts as u32, v14 stores C[] as u32."""
     import struct
