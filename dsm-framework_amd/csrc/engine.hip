@@ -2384,6 +2384,10 @@ class Engine {
             carena.cap = (arena.cap / 16) & ~(size_t)255;
             arena.cap -= carena.cap;
             carena.base = arena.base + arena.cap;
+            if (const char* e = getenv("DSM_CAND_ARENA")) {   // test hook: a block so small that levels overflow it (they are stored the old way)
+                const size_t want = (size_t)atol(e) & ~(size_t)255;
+                if (want < carena.cap) carena.cap = want;
+            }
         }
         // (timing events without the system-scope fence a default event carries: the records bracket every LF-step launch, and a
         // fence there would write the L2 back twice per level)
@@ -3119,7 +3123,10 @@ class Engine {
         me.ncand = (u32)(tot & 0xFFFFFFFFu);
         me.npairs = (u32)(tot >> 32);
         if (stored_cap && me.ncand <= stored_cap) {   // the block is cut to the records the level has
-            if (me.ncand) me.crec = carena.get<uint4>(me.ncand);
+            if (me.ncand) {
+                me.crec = carena.get<uint4>(me.ncand);   // (cap and offsets are multiples of the allocation granule: what fitted the block fits here)
+                if (!me.crec) return fail(DSM_E_HIP, "candidate arena: the block that held the records cannot be claimed");
+            }
             stats.candidates += me.ncand;
             return 0;
         }

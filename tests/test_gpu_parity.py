@@ -355,6 +355,35 @@ def test_dense_sweep_of_a_thin_sample(pydsm_mod, tmp_path, monkeypatch):
         ix.close()
 
 
+def test_candidate_block_overflow_falls_back(pydsm_mod, tmp_path, monkeypatch):
+    """One sample: the advance sweep stores a level's candidates in a block of their own arena, taken before their number is known.  A
+    block too small for a level (DSM_CAND_ARENA: 16 KB = 1024 records, then nothing at all) makes that level store them the old way
+    (scan of the words, cand_store_kernel); levels that fit and levels that do not alternate within one prefix."""
+    from pydsm import builder
+    import torch
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 40000)
+    st = rng.integers(0, len(genome) - 60, 20000)
+    codes = np.stack([genome[a:a + 60] for a in st]).astype(np.uint8)
+    p = tmp_path / "one.fasta.fmi"
+    builder.build_from_codes(torch.from_numpy(codes), str(p))
+    o = orc.Index(str(p))
+    with pydsm_mod.Index(str(p)) as g:
+        want = {}
+        for pre in ("", "C"):
+            want[pre] = orc.mine([o], [g.name], [pre], fmin=2, pmin=1, emax=2.0)
+        for arena in (None, "16384", "256"):
+            if arena:
+                monkeypatch.setenv("DSM_CAND_ARENA", arena)
+            for pre in ("", "C"):
+                got, st_ = pydsm_mod.mine([g], pre, fmin=2, pmin=1, emax=2.0)
+                w, ost = want[pre]
+                assert got == w, (arena, pre)
+                assert (st_.reported, st_.lf_steps, st_.rank_ops, st_.union_nodes, st_.tuples, st_.pairs) == ost, (arena, pre)
+                assert st_.max_frontier > 5000 and st_.tuples > 2000
+    o.close()
+
+
 def _downgrade_fmi(raw, ver):
     """Rewrite a v17 .fmi as v16 / v15 / v14 (FMIndex.cpp:267-290, HuffWT.h:21-37): v<16 stores code counts as u32, v14 stores C[] as u32."""
     import struct
