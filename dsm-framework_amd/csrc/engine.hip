@@ -1686,7 +1686,8 @@ static int emit_job(HostPool& pool, EmitSet& E, int c, u32 d, double emin, doubl
             if (!k) ++ndrop;
         }
     }
-    if (getenv("DSM_TIMELINE")) { char msg[96]; snprintf(msg, sizeof msg, "nt=%u dropped=%llu host=%u", nt, (unsigned long long)ndrop, counts[1]); timeline("  emitter: verdicts", msg); }
+    static const bool tl_on = getenv("DSM_TIMELINE") != nullptr;
+    if (tl_on) { char msg[96]; snprintf(msg, sizeof msg, "nt=%u dropped=%llu host=%u", nt, (unsigned long long)ndrop, counts[1]); timeline("  emitter: verdicts", msg); }
     u64 W = nt, QW = rel_pair[nt];
     u32* o_path = rel_path;
     u32* o_pair = rel_pair;
