@@ -41,6 +41,7 @@
 #include "entropy_tables.h"
 #include "textemit.h"
 #include "engine_api.h"
+#include "emit_runs.h"
 
 namespace dsm {
 
@@ -1700,33 +1701,17 @@ static int emit_job(HostPool& pool, EmitSet& E, int c, u32 d, double emin, doubl
         // A handful of tuples dropped among millions (one sample: the few nodes of four million occurrences and more, which only the
         // host's libm can decide): the runs of kept tuples between them leave as batches of their own, in place -- only the offsets of
         // a run are rebased to its first tuple (8 bytes per tuple instead of moving the ~55 bytes of every tuple behind the first drop).
-        std::vector<u32> seg;   // runs [seg[2i], seg[2i+1]) of kept tuples
-        {
-            u32 from = 0;
-            for (u8* q = keep; (q = (u8*)memchr(q, EV_DROP, (size_t)(keep + nt - q))) != nullptr; ++q) {
-                const u32 r = (u32)(q - keep);
-                if (r > from) { seg.push_back(from); seg.push_back(r); }
-                from = r + 1;
-            }
-            if (nt > from) { seg.push_back(from); seg.push_back(nt); }
-        }
+        std::vector<u32> seg;   // runs [seg[2i], seg[2i+1]) of kept tuples (emit_runs.h)
+        kept_runs(keep, nt, EV_DROP, seg);
         const size_t ns = seg.size() / 2;
         std::vector<u32> bp(ns), bq(ns);
         for (size_t i = 0; i < ns; ++i) { bp[i] = rel_path[seg[2 * i]]; bq[i] = rel_pair[seg[2 * i]]; }
         unsigned nth = host_threads();
         if (nt < 65536) nth = 1;
         const u32 per = (nt + nth - 1) / nth;
-        auto rebase = [&](unsigned t) {   // entries lo .. hi - 1 of this thread; a run owns the entries seg[2i] .. seg[2i+1] (its closing one included)
+        auto rebase = [&](unsigned t) {   // entries lo .. hi - 1 of this thread (the last one takes the closing entry nt)
             const u32 lo = t * per < nt ? t * per : nt, hi = t + 1 == nth ? nt + 1 : (lo + per < nt ? lo + per : nt);
-            size_t i = (size_t)(std::upper_bound(seg.begin(), seg.end(), lo) - seg.begin());  // first boundary beyond lo
-            i = i / 2;  // the run that contains lo, or the next one
-            if (i > 0 && lo <= seg[2 * (i - 1) + 1]) --i;
-            for (; i < ns && seg[2 * i] < hi; ++i) {
-                const u32 a = seg[2 * i] > lo ? seg[2 * i] : lo, b = seg[2 * i + 1] + 1 < hi ? seg[2 * i + 1] + 1 : hi;
-                const u32 sp_ = bp[i], sq_ = bq[i];
-                if (!sp_ && !sq_) continue;
-                for (u32 r = a; r < b; ++r) { rel_path[r] -= sp_; rel_pair[r] -= sq_; }
-            }
+            rebase_runs(rel_path, rel_pair, seg, bp, bq, lo, hi);
         };
         pool.run(nth, rebase);
         clock_gettime(CLOCK_MONOTONIC, &t1);

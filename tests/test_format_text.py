@@ -23,6 +23,15 @@ def test_integer_only_percent_f_equals_snprintf(tmp_path_factory):
     assert int(out.split()[1]) > 3000000
 
 
+def test_kept_runs_of_a_chunk_on_the_cpu(tmp_path_factory):
+    """csrc/emit_runs.h (the emitter's in-place batches when a handful of a chunk's tuples are dropped): run boundaries and the offsets'
+    rebasing, split over 1..17 callers in any order, against a direct restatement (tests/native/emit_runs_check.cpp)."""
+    exe = str(tmp_path_factory.mktemp("native") / "emit_runs_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "emit_runs_check.cpp")], check=True)
+    out = subprocess.run([exe, "4000", "7"], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok 4000 cases"), out
+
+
 def _batch(pydsm, ent, path_len, pairs_per, rng):
     nt = len(ent)
     pl = rng.integers(0, path_len + 1, nt).astype(np.uint32)
